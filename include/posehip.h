@@ -1,0 +1,139 @@
+/*
+ * posehip.h -- C ABI of libposehip.so: the MI355X (gfx950) implementation of the
+ * correspondence-and-pose hot path of seqwalt/PoseEstimation.
+ *
+ * The reference has no FFI layer of its own; the boundary it would bind is the
+ * pair of OpenCV calls on its hot path.  Every entry point names the reference
+ * call site it replaces (paths relative to the reference tree):
+ *
+ *   src/cereal_box.cpp:53        DescriptorMatcher::create("BruteForce-Hamming")
+ *   src/cereal_box.cpp:344       matcher->match(descriptors, descriptorsOld, matches)
+ *   src/cereal_box.cpp:345-356   min-distance filter on the match list
+ *   src/orb_feature_matching/matcher.py:18,21   BFMatcher(NORM_HAMMING, crossCheck=True).match
+ *   src/cereal_box.cpp:292-295 + docs/index.md:75,120
+ *                                cv::solvePnPRansac(..., SOLVEPNP_EPNP) (EPnP branch)
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer it passes in;
+ *   - no call throws; each returns a ph_status, and ph_last_error_string()
+ *     describes the last failure on the calling thread;
+ *   - "host" entry points take host pointers and copy in/out themselves;
+ *     "_dev" entry points take device pointers (HBM-resident) and a HIP stream
+ *     (NULL = the library's own stream) and return after enqueueing unless
+ *     stated otherwise;
+ *   - descriptors are 256-bit ORB rows: 32 bytes each, row stride >= 32;
+ *   - calls are serialised per process by an internal mutex and may come from
+ *     any thread (the reference calls from a std::async worker,
+ *     src/cereal_box.cpp:280).
+ */
+#ifndef POSEHIP_H
+#define POSEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PH_OK = 0,
+    PH_ERR_INVALID_ARG = 1,
+    PH_ERR_HIP = 2,
+    PH_ERR_NO_DEVICE = 3,
+    PH_ERR_NOT_INITIALIZED = 4,
+    PH_ERR_TOO_LARGE = 5
+} ph_status;
+
+/* Layout-compatible with cv::DMatch (16 bytes). */
+typedef struct {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;
+    float distance;
+} ph_dmatch;
+
+#define PH_NO_MATCH_IDX (-1)
+#define PH_NO_MATCH_DIST 2147483647
+
+/* ---- lifetime ------------------------------------------------------------ */
+
+/* Binds the calling process to one GPU and creates the library's stream and
+ * workspace.  Replaces the matcher construction at src/cereal_box.cpp:53.
+ * May be called again with the same device (no-op). */
+ph_status ph_init(int device);
+void ph_shutdown(void);
+const char *ph_last_error_string(void);
+/* Device the library is bound to, or -1. */
+int ph_device(void);
+
+/* ---- descriptor matching, host buffers ----------------------------------- */
+
+/* knnMatch(query, train, k) for k = 1 or 2 (cv::DescriptorMatcher::knnMatch;
+ * k=1 is the arithmetic of src/cereal_box.cpp:344).  out_idx/out_dist hold
+ * nq*k entries, row-major per query, best first; lowest train index wins among
+ * equal distances.  Slots beyond min(k, nt) hold PH_NO_MATCH_IDX /
+ * PH_NO_MATCH_DIST.  nq == 0 or nt == 0 is not an error. */
+ph_status ph_knn_hamming256(const uint8_t *query, int nq, size_t q_step, const uint8_t *train,
+                            int nt, size_t t_step, int k, int32_t *out_idx, int32_t *out_dist);
+
+/* match(query, train) without cross-check: src/cereal_box.cpp:344.
+ * out holds nq entries; *n_out = nq when nt > 0, else 0. */
+ph_status ph_match_hamming256(const uint8_t *query, int nq, size_t q_step, const uint8_t *train,
+                              int nt, size_t t_step, ph_dmatch *out, int *n_out);
+
+/* match(query, train) of a matcher built with crossCheck=true:
+ * src/orb_feature_matching/matcher.py:18,21.  out holds up to nq entries in
+ * ascending queryIdx; queries without a surviving pair are dropped. */
+ph_status ph_match_crosscheck_hamming256(const uint8_t *query, int nq, size_t q_step,
+                                         const uint8_t *train, int nt, size_t t_step,
+                                         ph_dmatch *out, int *n_out);
+
+/* knnMatch(k=2) followed by Lowe's ratio test (keep m[0] iff
+ * m[0].distance < ratio * m[1].distance, float arithmetic).  The reference has
+ * no ratio test; the benchmark configuration "kNN k=2 ratio test" defines it.
+ * out holds up to nq entries in ascending queryIdx. */
+ph_status ph_knn2_ratio_hamming256(const uint8_t *query, int nq, size_t q_step,
+                                   const uint8_t *train, int nt, size_t t_step, float ratio,
+                                   ph_dmatch *out, int *n_out);
+
+/* The filter of src/cereal_box.cpp:345-356 with explicit bounds: keep
+ * distance <= max(2*min_dist, 30.0).  Host-only (at most a few hundred
+ * elements in the reference).  out holds up to n entries; out may equal m. */
+ph_status ph_min_dist_filter(const ph_dmatch *m, int n, ph_dmatch *out, int *n_out);
+
+/* ---- descriptor matching, device buffers --------------------------------- */
+
+/* Same result as ph_knn_hamming256 with HBM-resident inputs and outputs.
+ * d_query / d_train: packed rows (stride 32 bytes), 16-byte aligned.
+ * train_index_base is added to every emitted train index (train-set shards
+ * report global indices).  d_keep may be NULL; otherwise k must be 2 and
+ * d_keep[i] (one byte per query) is set to 1 iff the ratio test with `ratio`
+ * passes.  Enqueues on `stream` (a hipStream_t, NULL = library stream) and
+ * returns without waiting; the library workspace is reused by the next call,
+ * so calls on different streams must not overlap. */
+ph_status ph_knn_hamming256_dev(const void *d_query, int64_t nq, const void *d_train, int64_t nt,
+                                int k, int32_t train_index_base, int32_t *d_out_idx,
+                                int32_t *d_out_dist, uint8_t *d_keep, float ratio, void *stream);
+
+/* Merge per-shard k-NN candidate lists (the step after the all-gather of a
+ * train-sharded search).  d_cand_idx / d_cand_dist: [n_shards][nq][k], shards
+ * ordered by ascending train index range, indices global.  Output as
+ * ph_knn_hamming256_dev.  Lowest index wins among equal distances. */
+ph_status ph_knn_merge_dev(const int32_t *d_cand_idx, const int32_t *d_cand_dist, int n_shards,
+                           int64_t nq, int k, int32_t *d_out_idx, int32_t *d_out_dist,
+                           uint8_t *d_keep, float ratio, void *stream);
+
+/* Cross-check match on device buffers: d_out_idx[q] = matched train index or
+ * PH_NO_MATCH_IDX, d_out_dist[q] its distance (not compacted). */
+ph_status ph_match_crosscheck_hamming256_dev(const void *d_query, int64_t nq, const void *d_train,
+                                             int64_t nt, int32_t *d_out_idx, int32_t *d_out_dist,
+                                             void *stream);
+
+/* Blocks until everything enqueued on `stream` (NULL = library stream) is done. */
+ph_status ph_stream_synchronize(void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEHIP_H */

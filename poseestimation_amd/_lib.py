@@ -1,0 +1,91 @@
+"""ctypes binding of libposehip.so (the C ABI declared in include/posehip.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, an
+exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libposehip.so")
+
+PH_OK = 0
+NO_MATCH_IDX = -1
+NO_MATCH_DIST = 2147483647
+
+
+class PosehipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"posehip status {status}: {message}")
+        self.status = status
+
+
+class DMatchC(C.Structure):
+    _fields_ = [("queryIdx", C.c_int32), ("trainIdx", C.c_int32), ("imgIdx", C.c_int32),
+                ("distance", C.c_float)]
+
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_dmp = C.POINTER(DMatchC)
+_intp = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); every symbol include/posehip.h declares.
+SIGNATURES = {
+    "ph_init": (C.c_int, [C.c_int]),
+    "ph_shutdown": (None, []),
+    "ph_last_error_string": (C.c_char_p, []),
+    "ph_device": (C.c_int, []),
+    "ph_knn_hamming256": (C.c_int, [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int, C.c_size_t, C.c_int,
+                                    _i32p, _i32p]),
+    "ph_match_hamming256": (C.c_int, [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int, C.c_size_t, _dmp,
+                                      _intp]),
+    "ph_match_crosscheck_hamming256": (C.c_int, [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int,
+                                                 C.c_size_t, _dmp, _intp]),
+    "ph_knn2_ratio_hamming256": (C.c_int, [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int, C.c_size_t,
+                                           C.c_float, _dmp, _intp]),
+    "ph_min_dist_filter": (C.c_int, [_dmp, C.c_int, _dmp, _intp]),
+    "ph_knn_hamming256_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
+                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                        C.c_void_p]),
+    "ph_knn_merge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "ph_match_crosscheck_hamming256_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ph_stream_synchronize": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libposehip.so and declares the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C poseestimation_amd/csrc` "
+            "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != PH_OK:
+        raise PosehipError(status, load().ph_last_error_string().decode("utf-8", "replace"))
+
+
+def init(device=0):
+    check(load().ph_init(int(device)))
+
+
+def shutdown():
+    load().ph_shutdown()

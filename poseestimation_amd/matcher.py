@@ -1,0 +1,150 @@
+"""Host-side mirror of the OpenCV matcher interface the reference calls.
+
+Reference call sites (paths in the reference tree):
+  src/orb_feature_matching/matcher.py:18   bf = cv.BFMatcher(cv.NORM_HAMMING, crossCheck=True)
+  src/orb_feature_matching/matcher.py:21   matches = bf.match(des1, des2)
+  src/orb_feature_matching/matcher.py:24   sorted(matches, key=lambda x: x.distance)
+  src/cereal_box.cpp:53,344                DescriptorMatcher::create("BruteForce-Hamming")->match
+  src/cereal_box.cpp:345-356               min-distance filter
+
+Same names, argument meaning and error behaviour as cv2 for this path; the
+arithmetic runs in libposehip.so on the GPU (no CPU fallback).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+NORM_HAMMING = 6  # cv2.NORM_HAMMING
+
+
+class DMatch:
+    """cv2.DMatch: queryIdx, trainIdx, imgIdx, distance."""
+    __slots__ = ("queryIdx", "trainIdx", "imgIdx", "distance")
+
+    def __init__(self, queryIdx=-1, trainIdx=-1, imgIdx=-1, distance=float("inf")):
+        self.queryIdx = int(queryIdx)
+        self.trainIdx = int(trainIdx)
+        self.imgIdx = int(imgIdx)
+        self.distance = float(distance)
+
+    def __repr__(self):
+        return (f"DMatch(queryIdx={self.queryIdx}, trainIdx={self.trainIdx}, "
+                f"imgIdx={self.imgIdx}, distance={self.distance})")
+
+    def __eq__(self, other):
+        return (isinstance(other, DMatch) and self.queryIdx == other.queryIdx
+                and self.trainIdx == other.trainIdx and self.imgIdx == other.imgIdx
+                and self.distance == other.distance)
+
+
+def _as_descriptors(a, name):
+    """uint8 [N, 32] with unit column stride; returns (array, rows, row stride)."""
+    if a is None:
+        return np.zeros((0, 32), np.uint8), 0, 32
+    a = np.asarray(a)
+    if a.size == 0:
+        return np.zeros((0, 32), np.uint8), 0, 32
+    if a.dtype != np.uint8 or a.ndim != 2 or a.shape[1] != 32:
+        # cv2 raises cv2.error from a CV_Assert on type/cols mismatch
+        raise ValueError(f"{name}: expected uint8 array of shape [N, 32] (256-bit ORB "
+                         f"descriptors), got dtype={a.dtype} shape={a.shape}")
+    if a.strides[1] != 1 or a.strides[0] < 32:
+        a = np.ascontiguousarray(a)
+    return a, a.shape[0], a.strides[0]
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _dm_list(buf, n):
+    return [DMatch(m.queryIdx, m.trainIdx, m.imgIdx, m.distance) for m in buf[:n]]
+
+
+class BFMatcher:
+    """cv2.BFMatcher restricted to NORM_HAMMING on 256-bit descriptors."""
+
+    def __init__(self, normType=NORM_HAMMING, crossCheck=False):
+        if normType != NORM_HAMMING:
+            raise ValueError("only NORM_HAMMING is implemented (the reference uses no other norm)")
+        self.normType = normType
+        self.crossCheck = bool(crossCheck)
+        lib = _lib.load()
+        if lib.ph_device() < 0:
+            _lib.init(0)
+
+    def match(self, queryDescriptors, trainDescriptors):
+        q, nq, qs = _as_descriptors(queryDescriptors, "queryDescriptors")
+        t, nt, ts = _as_descriptors(trainDescriptors, "trainDescriptors")
+        lib = _lib.load()
+        out = (_lib.DMatchC * max(nq, 1))()
+        n = C.c_int(0)
+        fn = lib.ph_match_crosscheck_hamming256 if self.crossCheck else lib.ph_match_hamming256
+        _lib.check(fn(_u8(q), nq, qs, _u8(t), nt, ts, out, C.byref(n)))
+        return _dm_list(out, n.value)
+
+    def knnMatch(self, queryDescriptors, trainDescriptors, k):
+        if self.crossCheck and k != 1:
+            # BFMatcher::knnMatchImpl asserts K == 1 when crossCheck is set
+            raise ValueError("crossCheck requires k == 1")
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        if k > 2:
+            raise ValueError("k > 2 is not implemented (the hot path uses k = 1 and k = 2)")
+        if self.crossCheck:
+            return [[m] for m in self.match(queryDescriptors, trainDescriptors)]
+        q, nq, qs = _as_descriptors(queryDescriptors, "queryDescriptors")
+        t, nt, ts = _as_descriptors(trainDescriptors, "trainDescriptors")
+        if nq == 0 or nt == 0:
+            return []
+        idx = np.empty((nq, k), np.int32)
+        dist = np.empty((nq, k), np.int32)
+        i32 = C.POINTER(C.c_int32)
+        _lib.check(_lib.load().ph_knn_hamming256(_u8(q), nq, qs, _u8(t), nt, ts, k,
+                                                 idx.ctypes.data_as(i32),
+                                                 dist.ctypes.data_as(i32)))
+        rows = []
+        for i in range(nq):
+            rows.append([DMatch(i, int(idx[i, r]), 0, float(dist[i, r]))
+                         for r in range(k) if idx[i, r] >= 0])
+        return rows
+
+    def knnMatchArrays(self, queryDescriptors, trainDescriptors, k):
+        """knnMatch as (idx[nq,k], dist[nq,k]) int32 arrays; -1 / INT_MAX mark empty slots."""
+        q, nq, qs = _as_descriptors(queryDescriptors, "queryDescriptors")
+        t, nt, ts = _as_descriptors(trainDescriptors, "trainDescriptors")
+        idx = np.full((nq, k), _lib.NO_MATCH_IDX, np.int32)
+        dist = np.full((nq, k), _lib.NO_MATCH_DIST, np.int32)
+        i32 = C.POINTER(C.c_int32)
+        _lib.check(_lib.load().ph_knn_hamming256(_u8(q), nq, qs, _u8(t), nt, ts, k,
+                                                 idx.ctypes.data_as(i32),
+                                                 dist.ctypes.data_as(i32)))
+        return idx, dist
+
+
+def ratio_test_match(queryDescriptors, trainDescriptors, ratio=0.75):
+    """knnMatch(k=2) + Lowe ratio test (m.distance < ratio * n.distance).
+
+    Not in the reference; the ratio default 0.75 is this build's choice.
+    """
+    q, nq, qs = _as_descriptors(queryDescriptors, "queryDescriptors")
+    t, nt, ts = _as_descriptors(trainDescriptors, "trainDescriptors")
+    out = (_lib.DMatchC * max(nq, 1))()
+    n = C.c_int(0)
+    _lib.check(_lib.load().ph_knn2_ratio_hamming256(_u8(q), nq, qs, _u8(t), nt, ts,
+                                                    float(ratio), out, C.byref(n)))
+    return _dm_list(out, n.value)
+
+
+def min_dist_filter(matches):
+    """good_matches of src/cereal_box.cpp:345-356: distance <= max(2*min_dist, 30.0)."""
+    n = len(matches)
+    buf = (_lib.DMatchC * max(n, 1))()
+    for i, m in enumerate(matches):
+        buf[i] = _lib.DMatchC(m.queryIdx, m.trainIdx, m.imgIdx, m.distance)
+    out = (_lib.DMatchC * max(n, 1))()
+    k = C.c_int(0)
+    _lib.check(_lib.load().ph_min_dist_filter(buf, n, out, C.byref(k)))
+    return _dm_list(out, k.value)

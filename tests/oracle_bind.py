@@ -1,0 +1,121 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU checker used by the tests.
+
+Test infrastructure only: nothing under poseestimation_amd/ imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class DMatchC(C.Structure):
+    _fields_ = [("queryIdx", C.c_int32), ("trainIdx", C.c_int32), ("imgIdx", C.c_int32),
+                ("distance", C.c_float)]
+
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_dmp = C.POINTER(DMatchC)
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(".c")]
+    stale = (not os.path.exists(LIB_PATH)
+             or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
+    if stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(LIB_PATH)
+    lib.orc_knn_hamming256.restype = C.c_int
+    lib.orc_knn_hamming256.argtypes = [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int, C.c_size_t,
+                                       C.c_int, _i32p, _i32p]
+    lib.orc_knn_hamming256_mt.restype = C.c_int
+    lib.orc_knn_hamming256_mt.argtypes = lib.orc_knn_hamming256.argtypes + [C.c_int]
+    for name in ("orc_match", "orc_match_crosscheck"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int, C.c_size_t, _dmp]
+    lib.orc_ratio_filter.restype = C.c_int
+    lib.orc_ratio_filter.argtypes = [_i32p, _i32p, C.c_int, C.c_float, _dmp]
+    lib.orc_min_dist_filter.restype = C.c_int
+    lib.orc_min_dist_filter.argtypes = [_dmp, C.c_int, _dmp]
+    lib.orc_sort_by_distance.restype = None
+    lib.orc_sort_by_distance.argtypes = [_dmp, C.c_int]
+    _lib = lib
+    return lib
+
+
+def _rows(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, 32) if np.size(a) else \
+        np.zeros((0, 32), np.uint8)
+    return a, a.shape[0]
+
+
+def _p(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def knn(q, t, k, threads=1):
+    """(idx[nq,k], dist[nq,k]) int32; -1 / INT_MAX mark empty slots."""
+    q, nq = _rows(q)
+    t, nt = _rows(t)
+    idx = np.full((nq, k), -1, np.int32)
+    dist = np.full((nq, k), 2147483647, np.int32)
+    lib = load()
+    if threads > 1:
+        rc = lib.orc_knn_hamming256_mt(_p(q), nq, 32, _p(t), nt, 32, k,
+                                       idx.ctypes.data_as(_i32p), dist.ctypes.data_as(_i32p),
+                                       threads)
+    else:
+        rc = lib.orc_knn_hamming256(_p(q), nq, 32, _p(t), nt, 32, k, idx.ctypes.data_as(_i32p),
+                                    dist.ctypes.data_as(_i32p))
+    assert rc == 0
+    return idx, dist
+
+
+def _tuples(buf, n):
+    return [(m.queryIdx, m.trainIdx, m.imgIdx, m.distance) for m in buf[:n]]
+
+
+def match(q, t, cross_check=False):
+    """List of (queryIdx, trainIdx, imgIdx, distance)."""
+    q, nq = _rows(q)
+    t, nt = _rows(t)
+    out = (DMatchC * max(nq, 1))()
+    fn = load().orc_match_crosscheck if cross_check else load().orc_match
+    n = fn(_p(q), nq, 32, _p(t), nt, 32, out)
+    assert n >= 0
+    return _tuples(out, n)
+
+
+def ratio_filter(idx, dist, ratio):
+    idx = np.ascontiguousarray(idx, np.int32)
+    dist = np.ascontiguousarray(dist, np.int32)
+    nq = idx.shape[0]
+    out = (DMatchC * max(nq, 1))()
+    n = load().orc_ratio_filter(idx.ctypes.data_as(_i32p), dist.ctypes.data_as(_i32p), nq,
+                                float(ratio), out)
+    return _tuples(out, n)
+
+
+def min_dist_filter(matches):
+    n = len(matches)
+    buf = (DMatchC * max(n, 1))(*[DMatchC(*m) for m in matches])
+    out = (DMatchC * max(n, 1))()
+    k = load().orc_min_dist_filter(buf, n, out)
+    return _tuples(out, k)
+
+
+def sort_by_distance(matches):
+    n = len(matches)
+    buf = (DMatchC * max(n, 1))(*[DMatchC(*m) for m in matches])
+    load().orc_sort_by_distance(buf, n)
+    return _tuples(buf, n)

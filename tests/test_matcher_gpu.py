@@ -1,0 +1,177 @@
+"""GPU suite: the HIP matcher against the CPU oracle, bit-exact, through the C ABI."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+import oracle_bind as orc
+from test_oracle_matcher import KAT, rows
+
+pytestmark = pytest.mark.gpu
+
+INT_MAX = 2147483647
+
+
+def gpu_knn(lib, q, t, k):
+    nq, nt = q.shape[0], t.shape[0]
+    idx = np.full((nq, k), 12345, np.int32)
+    dist = np.full((nq, k), 12345, np.int32)
+    u8, i32 = C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    lib.check(lib.load().ph_knn_hamming256(q.ctypes.data_as(u8), nq, q.strides[0] if nq else 32,
+                                           t.ctypes.data_as(u8), nt, t.strides[0] if nt else 32,
+                                           k, idx.ctypes.data_as(i32), dist.ctypes.data_as(i32)))
+    return idx, dist
+
+
+def gpu_match(lib, q, t, cross_check=False, ratio=None):
+    nq, nt = q.shape[0], t.shape[0]
+    out = (lib.DMatchC * max(nq, 1))()
+    n = C.c_int(-1)
+    u8 = C.POINTER(C.c_uint8)
+    args = (q.ctypes.data_as(u8), nq, q.strides[0] if nq else 32, t.ctypes.data_as(u8), nt,
+            t.strides[0] if nt else 32)
+    if ratio is not None:
+        st = lib.load().ph_knn2_ratio_hamming256(*args, float(ratio), out, C.byref(n))
+    elif cross_check:
+        st = lib.load().ph_match_crosscheck_hamming256(*args, out, C.byref(n))
+    else:
+        st = lib.load().ph_match_hamming256(*args, out, C.byref(n))
+    lib.check(st)
+    return [(m.queryIdx, m.trainIdx, m.imgIdx, m.distance) for m in out[:n.value]]
+
+
+@pytest.mark.parametrize("case", KAT["cases"], ids=[c["name"] for c in KAT["cases"]])
+def test_known_answers(posehip, case):
+    q, t = rows(case["query"]), rows(case["train"])
+    idx, dist = gpu_knn(posehip, q, t, 2)
+    assert idx.tolist() == case["knn2_idx"]
+    assert dist.tolist() == case["knn2_dist"]
+    assert gpu_match(posehip, q, t) == [(a, b, 0, float(d)) for a, b, d in case["match"]]
+    assert gpu_match(posehip, q, t, cross_check=True) == [(a, b, 0, float(d))
+                                                          for a, b, d in case["crosscheck"]]
+
+
+SHAPES = [(1, 1), (1, 2), (2, 1), (63, 65), (64, 64), (257, 255), (500, 500), (1000, 3),
+          (3, 1000), (500, 4099), (2049, 2051)]
+
+
+@pytest.mark.parametrize("nq,nt", SHAPES)
+@pytest.mark.parametrize("k", [1, 2])
+def test_random_parity(posehip, nq, nt, k):
+    q = datagen.random_descriptors(nq, 11 + nq)
+    t = datagen.random_descriptors(nt, 13 + nt)
+    idx, dist = gpu_knn(posehip, q, t, k)
+    ridx, rdist = orc.knn(q, t, k)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist, rdist)
+
+
+@pytest.mark.parametrize("nq,nt", [(300, 700), (1000, 1000)])
+def test_tie_stress_parity(posehip, nq, nt):
+    q = datagen.codebook_descriptors(nq, 21)
+    t = datagen.codebook_descriptors(nt, 22)
+    idx, dist = gpu_knn(posehip, q, t, 2)
+    ridx, rdist = orc.knn(q, t, 2)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist, rdist)
+
+
+def test_all_identical_rows(posehip):
+    q = np.tile(datagen.random_descriptors(1, 5), (130, 1))
+    t = np.tile(q[:1], (777, 1))
+    idx, dist = gpu_knn(posehip, q, t, 2)
+    assert (idx == np.array([0, 1])).all() and (dist == 0).all()
+
+
+@pytest.mark.parametrize("nq,nt,seed", [(500, 500, 1), (500, 431, 2), (77, 500, 3), (1500, 1200, 4)])
+def test_match_and_crosscheck_parity(posehip, nq, nt, seed):
+    q = datagen.random_descriptors(nq, seed)
+    t = datagen.perturbed_copy(q, seed + 50)
+    if nt <= nq:
+        t = t[:nt]
+    else:
+        t = np.concatenate([t, datagen.random_descriptors(nt - nq, seed + 60)])
+    assert gpu_match(posehip, q, t) == orc.match(q, t)
+    got = gpu_match(posehip, q, t, cross_check=True)
+    want = orc.match(q, t, cross_check=True)
+    assert got == want
+    assert 0 < len(got) <= nq
+
+
+def test_crosscheck_tie_stress(posehip):
+    q = datagen.codebook_descriptors(300, 31, words=8)
+    t = datagen.codebook_descriptors(280, 32, words=8)
+    assert gpu_match(posehip, q, t, cross_check=True) == orc.match(q, t, cross_check=True)
+
+
+@pytest.mark.parametrize("ratio", [0.75, 0.8, 1.0])
+def test_ratio_parity(posehip, ratio):
+    q = datagen.random_descriptors(800, 41)
+    t = np.concatenate([datagen.perturbed_copy(q, 42)[:500], datagen.random_descriptors(900, 43)])
+    got = gpu_match(posehip, q, t, ratio=ratio)
+    ridx, rdist = orc.knn(q, t, 2)
+    assert got == orc.ratio_filter(ridx, rdist, ratio)
+    if ratio < 1.0:
+        assert 0 < len(got) < 800
+
+
+def test_empty_and_degenerate(posehip):
+    q = datagen.random_descriptors(5, 1)
+    e = np.zeros((0, 32), np.uint8)
+    assert gpu_match(posehip, q, e) == []
+    assert gpu_match(posehip, e, q) == []
+    assert gpu_match(posehip, q, e, cross_check=True) == []
+    assert gpu_match(posehip, q, e, ratio=0.75) == []
+    idx, dist = gpu_knn(posehip, q, e, 2)
+    assert (idx == -1).all() and (dist == INT_MAX).all()
+
+
+def test_strided_rows(posehip):
+    """cv::Mat rows may be padded (step > 32)."""
+    big = datagen.random_descriptors(400, 77).reshape(200, 64)
+    q = big[:, :32]           # stride 64
+    t = datagen.random_descriptors(300, 78)
+    assert q.strides[0] == 64
+    idx, dist = gpu_knn(posehip, q, t, 2)
+    ridx, rdist = orc.knn(np.ascontiguousarray(q), t, 2)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+
+
+def test_invalid_arguments(posehip):
+    lib = posehip.load()
+    q = datagen.random_descriptors(4, 1)
+    u8, i32 = C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    out = np.zeros(16, np.int32)
+    st = lib.ph_knn_hamming256(q.ctypes.data_as(u8), 4, 32, q.ctypes.data_as(u8), 4, 32, 3,
+                               out.ctypes.data_as(i32), out.ctypes.data_as(i32))
+    assert st == 1 and b"k must be" in lib.ph_last_error_string()
+    st = lib.ph_knn_hamming256(q.ctypes.data_as(u8), 4, 16, q.ctypes.data_as(u8), 4, 32, 1,
+                               out.ctypes.data_as(i32), out.ctypes.data_as(i32))
+    assert st == 1
+    st = lib.ph_knn_hamming256(None, 4, 32, q.ctypes.data_as(u8), 4, 32, 1,
+                               out.ctypes.data_as(i32), out.ctypes.data_as(i32))
+    assert st == 1
+
+
+def test_python_mirror_matches_reference_script_flow(posehip):
+    """The flow of src/orb_feature_matching/matcher.py:18-24 through the Python mirror."""
+    import poseestimation_amd as pa
+    des1 = datagen.random_descriptors(500, 91)
+    des2 = datagen.perturbed_copy(des1, 92)
+    bf = pa.BFMatcher(pa.NORM_HAMMING, crossCheck=True)
+    matches = bf.match(des1, des2)
+    matches = sorted(matches, key=lambda x: x.distance)
+    want = orc.sort_by_distance(orc.match(des1, des2, cross_check=True))
+    assert [(m.queryIdx, m.trainIdx, m.imgIdx, m.distance) for m in matches] == want
+    # and the C++ flow of src/cereal_box.cpp:344-356
+    plain = pa.BFMatcher(pa.NORM_HAMMING).match(des1, des2)
+    good = pa.min_dist_filter(plain)
+    wgood = orc.min_dist_filter(orc.match(des1, des2))
+    assert [(m.queryIdx, m.trainIdx, m.imgIdx, m.distance) for m in good] == wgood
+    rows2 = pa.BFMatcher().knnMatch(des1, des2, k=2)
+    ridx, rdist = orc.knn(des1, des2, 2)
+    assert [[m.trainIdx for m in r] for r in rows2] == ridx.tolist()
+    assert [[m.distance for m in r] for r in rows2] == rdist.astype(float).tolist()
