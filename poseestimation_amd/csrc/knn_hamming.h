@@ -6,22 +6,25 @@
 
 namespace posehip {
 
-// Threads per workgroup of the distance kernel (4 waves).
-static constexpr int KNN_BLOCK = 256;
+// Most waves per workgroup of the distance kernel.
+static constexpr int KNN_MAX_WAVES = 16;
 // Packed key = distance << KNN_KEY_SHIFT | train index local to a split.
 // distance <= 256 needs 9 bits, which leaves 22 index bits below 0xFFFFFFFF.
 static constexpr int KNN_KEY_SHIFT = 22;
 static constexpr int64_t KNN_MAX_ROWS_PER_SPLIT = (int64_t)1 << KNN_KEY_SHIFT;
 
 struct KnnPlan {
-    int qpl;                // query rows per lane
-    int64_t q_blocks;       // grid.x
+    int waves;              // waves per workgroup (all on the same 64 queries)
+    bool lazy;              // threshold-gated key update
+    int64_t q_blocks;       // grid.x: blocks of 64 queries
     int n_splits;           // grid.y: train-row splits
-    int64_t rows_per_split; // train rows per split
+    int64_t rows_per_split; // train rows per workgroup
+    int rows_per_wave;      // train rows per wave inside a split
     size_t part_bytes;      // workspace for per-split keys
 };
 
 KnnPlan knn_plan(int64_t nq, int64_t nt, int n_cus);
+KnnPlan knn_plan_custom(int64_t nq, int64_t nt, int waves, bool lazy, int64_t max_blocks);
 
 hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const void *d_train,
                       int64_t nt, int k, int32_t index_base, uint32_t *d_part, int32_t *d_out_idx,

@@ -5,8 +5,7 @@
 // reference (OpenCV batchDistance: popcount(a XOR b) over 32 bytes, K-best
 // list with strict '<' insertion => lowest train index wins ties).
 //
-// Mapping.  One query row per lane (QPL rows per lane), held in 8*QPL VGPRs
-// for the whole kernel.  Train rows are wave-uniform: they are fetched with
+// Mapping.  One query row per lane, held in 8 VGPRs for the whole kernel.  Train rows are wave-uniform: they are fetched with
 // scalar loads (s_load_dwordx8) into SGPRs and used directly as the scalar
 // operand of v_xor_b32, so the inner loop carries no vector-memory or LDS
 // instruction at all.  Per (query, train) pair the VALU executes
@@ -16,10 +15,10 @@
 // Keys order by (distance, train index), so min / median-of-three reproduce
 // the strict-'<' insertion rule exactly.
 //
-// A launch is a grid (query blocks) x (train splits); each workgroup writes
-// its two best keys per query for its split, and knn_merge_kernel folds the
-// splits in ascending train order.  Splits exist only to fill 256 CUs when the
-// query count alone cannot.
+// A launch is a grid (64-query blocks) x (train splits); the waves of a
+// workgroup share their 64 queries and split the workgroup's train rows, fold
+// their key pairs through LDS, and knn_merge_kernel folds the splits.  Splits
+// exist only to fill 256 CUs when the query count alone cannot.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -84,102 +83,135 @@ __device__ __forceinline__ void top2_update(uint32_t &m1, uint32_t &m2, uint32_t
     m1 = min(m1, key);
 }
 
-template <int UNROLL> struct RowGroup {
+static constexpr int UNROLL = 4; // train rows per SGPR group (2 x s_load_dwordx16)
+
+struct RowGroup {
     Row r[UNROLL];
 };
 
-template <int UNROLL>
-__device__ __forceinline__ void load_group(RowGroup<UNROLL> &g, const Row *__restrict__ rows)
+__device__ __forceinline__ void load_group(RowGroup &g, const Row *__restrict__ rows)
 {
 #pragma unroll
     for (int u = 0; u < UNROLL; u++)
         g.r[u] = rows[u];
 }
 
-template <int QPL, int UNROLL>
-__device__ __forceinline__ void eval_group(const RowGroup<UNROLL> &g, const uint32_t (&q)[QPL][8],
-                                           uint32_t (&m1)[QPL], uint32_t (&m2)[QPL], uint32_t j)
+// Eager form: every pair updates the running keys (19 VALU ops per pair).
+// Lazy form: the keys are touched only when some lane of the wave holds a
+// distance strictly below its current second-best distance (a later train row
+// with an equal distance can never enter, by the strict '<' rule), which costs
+// 16 + 3/UNROLL ops per pair plus a wave-uniform branch; it wins once a wave
+// streams enough train rows for candidates to become rare.
+template <bool LAZY>
+__device__ __forceinline__ void eval_group(const RowGroup &g, const uint32_t (&q)[8], uint32_t &m1,
+                                           uint32_t &m2, uint32_t &thr, uint32_t j)
 {
+    if constexpr (!LAZY) {
 #pragma unroll
-    for (int u = 0; u < UNROLL; u++) {
+        for (int u = 0; u < UNROLL; u++)
+            top2_update(m1, m2, make_key(hamming256(q, g.r[u]), j + u));
+    } else {
+        uint32_t d[UNROLL];
 #pragma unroll
-        for (int r = 0; r < QPL; r++) {
-            const uint32_t d = hamming256(q[r], g.r[u]);
-            top2_update(m1[r], m2[r], make_key(d, j + u));
+        for (int u = 0; u < UNROLL; u++)
+            d[u] = hamming256(q, g.r[u]);
+        uint32_t dmin = d[0];
+#pragma unroll
+        for (int u = 1; u < UNROLL; u++)
+            dmin = min(dmin, d[u]);
+        if (__builtin_amdgcn_ballot_w64(dmin < thr) != 0) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++)
+                top2_update(m1, m2, make_key(d[u], j + u));
+            thr = m2 >> KNN_KEY_SHIFT;
         }
     }
 }
 
-// part layout: [split][rank 0/1][nq] packed keys (dist << KEY_SHIFT | local index).
-template <int QPL, int UNROLL>
-__global__ __launch_bounds__(KNN_BLOCK) void knn_partial_kernel(const uint4 *__restrict__ query,
-                                                                const uint4 *__restrict__ train,
-                                                                int64_t nq, int64_t nt,
-                                                                int64_t rows_per_split,
-                                                                uint32_t *__restrict__ part)
+// Merges two ascending key pairs; keys are unique, so the result is exact.
+template <typename K> __device__ __forceinline__ void merge_pairs(K &a1, K &a2, K b1, K b2)
 {
-    const int64_t qbase = (int64_t)blockIdx.x * (KNN_BLOCK * QPL) + threadIdx.x;
+    const K lo = min(a1, b1);
+    const K hi = max(a1, b1);
+    a2 = min(hi, min(a2, b2));
+    a1 = lo;
+}
+
+// One workgroup = up to KNN_MAX_WAVES waves that hold the SAME 64 query rows
+// (one per lane) and each stream their own slice of the workgroup's train
+// split; the per-wave key pairs are folded through LDS and the workgroup
+// writes one pair per query: part[split][rank 0/1][nq], keys local to the split.
+template <bool LAZY>
+__global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_kernel(
+    const uint4 *__restrict__ query, const uint4 *__restrict__ train, int64_t nq, int64_t nt,
+    int64_t rows_per_split, int rows_per_wave, uint32_t *__restrict__ part)
+{
+    __shared__ uint32_t lds[2][KNN_MAX_WAVES][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = blockDim.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 64 + lane;
     const int split = blockIdx.y;
     const int64_t t0 = (int64_t)split * rows_per_split;
-    const int64_t t1 = min(nt, t0 + rows_per_split);
-    const int n = (int)(t1 - t0);
+    const int n_split = (int)min(nt - t0, rows_per_split);
+    const int w0 = wave * rows_per_wave;
+    const int n = max(0, min(n_split - w0, rows_per_wave));
 
-    uint32_t q[QPL][8];
-    uint32_t m1[QPL], m2[QPL];
-#pragma unroll
-    for (int r = 0; r < QPL; r++) {
-        const int64_t qi = qbase + (int64_t)r * KNN_BLOCK;
+    uint32_t q[8];
+    {
         uint4 a = make_uint4(0, 0, 0, 0), b = a;
         if (qi < nq) {
             a = query[2 * qi];
             b = query[2 * qi + 1];
         }
-        q[r][0] = a.x; q[r][1] = a.y; q[r][2] = a.z; q[r][3] = a.w;
-        q[r][4] = b.x; q[r][5] = b.y; q[r][6] = b.z; q[r][7] = b.w;
-        m1[r] = KEY_NONE;
-        m2[r] = KEY_NONE;
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
+        q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
     }
+    uint32_t m1 = KEY_NONE, m2 = KEY_NONE, thr = KEY_NONE >> KNN_KEY_SHIFT;
 
-    // Scalar loads return out of order, so the only usable wait is "all of
-    // them".  Two SGPR row groups alternate: the group for step g+1 is
-    // requested right after the wait that retires group g and flies while
-    // group g is evaluated.
-    const Row *__restrict__ rows = reinterpret_cast<const Row *>(train) + t0;
+    // Two SGPR row groups alternate (scalar loads return out of order, so the
+    // only usable wait is "all of them").
+    const Row *__restrict__ rows = reinterpret_cast<const Row *>(train) + t0 + w0;
     const int n_groups = n / UNROLL;
-    RowGroup<UNROLL> ga, gb;
+    RowGroup ga, gb;
     if (n_groups > 0)
         load_group(ga, rows);
     int g = 0;
     for (; g + 1 < n_groups; g += 2) {
         load_group(gb, rows + (g + 1) * UNROLL);
-        eval_group<QPL, UNROLL>(ga, q, m1, m2, (uint32_t)(g * UNROLL));
+        eval_group<LAZY>(ga, q, m1, m2, thr, (uint32_t)(w0 + g * UNROLL));
         if (g + 2 < n_groups)
             load_group(ga, rows + (g + 2) * UNROLL);
-        eval_group<QPL, UNROLL>(gb, q, m1, m2, (uint32_t)((g + 1) * UNROLL));
+        eval_group<LAZY>(gb, q, m1, m2, thr, (uint32_t)(w0 + (g + 1) * UNROLL));
     }
     if (g < n_groups)
-        eval_group<QPL, UNROLL>(ga, q, m1, m2, (uint32_t)(g * UNROLL));
+        eval_group<LAZY>(ga, q, m1, m2, thr, (uint32_t)(w0 + g * UNROLL));
     for (int j = n_groups * UNROLL; j < n; j++) {
-        RowGroup<1> t;
-        load_group(t, rows + j);
-        eval_group<QPL, 1>(t, q, m1, m2, (uint32_t)j);
+        const Row t = rows[j];
+        top2_update(m1, m2, make_key(hamming256(q, t), (uint32_t)(w0 + j)));
     }
 
-    uint32_t *p1 = part + ((int64_t)split * 2) * nq;
-    uint32_t *p2 = p1 + nq;
-#pragma unroll
-    for (int r = 0; r < QPL; r++) {
-        const int64_t qi = qbase + (int64_t)r * KNN_BLOCK;
-        if (qi < nq) {
-            p1[qi] = m1[r];
-            p2[qi] = m2[r];
-        }
+    if (n_waves > 1) {
+        lds[0][wave][lane] = m1;
+        lds[1][wave][lane] = m2;
+        __syncthreads();
+        if (wave != 0)
+            return;
+        for (int w = 1; w < n_waves; w++)
+            merge_pairs(m1, m2, lds[0][w][lane], lds[1][w][lane]);
+    }
+    if (qi < nq) {
+        uint32_t *p1 = part + ((int64_t)split * 2) * nq;
+        p1[qi] = m1;
+        p1[nq + qi] = m2;
     }
 }
 
-// Folds the per-split keys in ascending split order into the final k-NN rows.
-// A key from a later split never displaces an equal distance from an earlier
-// one (strict '<'), which is the lowest-train-index rule across splits.
+// Folds the per-split keys into the final k-NN rows.  Keys become
+// dist << 32 | global train index, so the smallest two keys ARE the OpenCV
+// answer (lowest train index among equal distances) whatever the fold order.
+// A workgroup covers 64 queries; its 4 waves take the splits round-robin and
+// are folded through LDS.
 __global__ __launch_bounds__(256) void knn_merge_kernel(const uint32_t *__restrict__ part,
                                                         int64_t nq, int n_splits,
                                                         int64_t rows_per_split, int k,
@@ -188,26 +220,32 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint32_t *__restri
                                                         int32_t *__restrict__ out_dist,
                                                         uint8_t *__restrict__ keep, float ratio)
 {
-    const int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (qi >= nq)
-        return;
-    // 64-bit keys: dist << 32 | global index; ~0 = none.
+    __shared__ uint64_t lds[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 64 + lane;
     uint64_t b1 = ~0ull, b2 = ~0ull;
-    for (int s = 0; s < n_splits; s++) {
-        const uint32_t *p = part + ((int64_t)s * 2) * nq;
-        const uint32_t k1 = p[qi], k2 = p[nq + qi];
-        const uint64_t base = (uint64_t)((int64_t)s * rows_per_split);
+    if (qi < nq) {
         const uint32_t mask = (1u << KNN_KEY_SHIFT) - 1;
-        const uint64_t g1 =
-            k1 == KEY_NONE ? ~0ull : ((uint64_t)(k1 >> KNN_KEY_SHIFT) << 32) | (base + (k1 & mask));
-        const uint64_t g2 =
-            k2 == KEY_NONE ? ~0ull : ((uint64_t)(k2 >> KNN_KEY_SHIFT) << 32) | (base + (k2 & mask));
-        // merge sorted pairs (b1<=b2), (g1<=g2)
-        const uint64_t lo = min(b1, g1);
-        const uint64_t hi = max(b1, g1);
-        b2 = min(hi, min(b2, g2));
-        b1 = lo;
+        for (int s = wave; s < n_splits; s += 4) {
+            const uint32_t *p = part + ((int64_t)s * 2) * nq;
+            const uint32_t k1 = p[qi], k2 = p[nq + qi];
+            const uint64_t base = (uint64_t)((int64_t)s * rows_per_split);
+            const uint64_t g1 = k1 == KEY_NONE
+                                    ? ~0ull
+                                    : ((uint64_t)(k1 >> KNN_KEY_SHIFT) << 32) | (base + (k1 & mask));
+            const uint64_t g2 = k2 == KEY_NONE
+                                    ? ~0ull
+                                    : ((uint64_t)(k2 >> KNN_KEY_SHIFT) << 32) | (base + (k2 & mask));
+            merge_pairs(b1, b2, g1, g2);
+        }
     }
+    lds[0][wave][lane] = b1;
+    lds[1][wave][lane] = b2;
+    __syncthreads();
+    if (wave != 0 || qi >= nq)
+        return;
+    for (int w = 1; w < 4; w++)
+        merge_pairs(b1, b2, lds[0][w][lane], lds[1][w][lane]);
     const int32_t i1 = b1 == ~0ull ? -1 : (int32_t)(uint32_t)b1 + index_base;
     const int32_t d1 = b1 == ~0ull ? 0x7FFFFFFF : (int32_t)(b1 >> 32);
     if (k == 1) {
@@ -217,10 +255,8 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint32_t *__restri
     }
     const int32_t i2 = b2 == ~0ull ? -1 : (int32_t)(uint32_t)b2 + index_base;
     const int32_t d2 = b2 == ~0ull ? 0x7FFFFFFF : (int32_t)(b2 >> 32);
-    out_idx[2 * qi] = i1;
-    out_idx[2 * qi + 1] = i2;
-    out_dist[2 * qi] = d1;
-    out_dist[2 * qi + 1] = d2;
+    *reinterpret_cast<int2 *>(out_idx + 2 * qi) = make_int2(i1, i2);
+    *reinterpret_cast<int2 *>(out_dist + 2 * qi) = make_int2(d1, d2);
     if (keep)
         keep[qi] = (i1 >= 0 && i2 >= 0 && (float)d1 < ratio * (float)d2) ? 1 : 0;
 }
@@ -310,31 +346,45 @@ __global__ __launch_bounds__(256) void cc_finalize_kernel(
 
 // ---- launchers ---------------------------------------------------------------
 
-KnnPlan knn_plan(int64_t nq, int64_t nt, int n_cus)
+KnnPlan knn_plan_custom(int64_t nq, int64_t nt, int waves, bool lazy, int64_t max_blocks)
 {
     KnnPlan p;
-    p.qpl = 1;
-    const int64_t rows_per_block = (int64_t)KNN_BLOCK * p.qpl;
-    p.q_blocks = (nq + rows_per_block - 1) / rows_per_block;
-    // Aim at >= 8 workgroups of 4 waves per CU; never split below 256 train
-    // rows per workgroup, never above the key's local-index range.
-    const int64_t want_blocks = (int64_t)n_cus * 8;
-    int64_t splits = (want_blocks + p.q_blocks - 1) / p.q_blocks;
-    const int64_t max_splits = (nt + 255) / 256;
+    p.waves = waves;
+    p.lazy = lazy;
+    p.q_blocks = (nq + 63) / 64;
+    // As many train splits as keep the grid within max_blocks (the workgroups
+    // that can be resident at once), each wave streaming >= 64 rows.
+    int64_t splits = max_blocks / p.q_blocks;
+    const int64_t max_splits = (nt + 64 * waves - 1) / (64 * waves);
     if (splits > max_splits)
         splits = max_splits;
+    if (splits > 65535)
+        splits = 65535;
     if (splits < 1)
         splits = 1;
     int64_t rows = (nt + splits - 1) / splits;
     if (rows > KNN_MAX_ROWS_PER_SPLIT)
         rows = KNN_MAX_ROWS_PER_SPLIT;
-    if (rows < 1)
-        rows = 1;
     p.rows_per_split = rows;
     p.n_splits = (int)((nt + rows - 1) / rows);
-    if (p.n_splits < 1)
-        p.n_splits = 1;
+    // per-wave slice, a multiple of the SGPR group so only the last wave has a tail
+    int64_t rw = (rows + waves - 1) / waves;
+    rw = (rw + 3) & ~(int64_t)3;
+    p.rows_per_wave = (int)rw;
     p.part_bytes = (size_t)p.n_splits * 2 * (size_t)nq * sizeof(uint32_t);
+    return p;
+}
+
+KnnPlan knn_plan(int64_t nq, int64_t nt, int n_cus)
+{
+    // 4-wave workgroups, 8 resident per CU (8 waves per SIMD).  When one split
+    // already gives every wave thousands of rows, 8-wave workgroups halve the
+    // rows per wave for the same residency; the lazy key update pays once a
+    // wave streams about a thousand rows.
+    KnnPlan p = knn_plan_custom(nq, nt, 4, false, (int64_t)n_cus * 8);
+    if (p.rows_per_wave >= 8192)
+        p = knn_plan_custom(nq, nt, 8, false, (int64_t)n_cus * 4);
+    p.lazy = p.rows_per_wave >= 1024;
     return p;
 }
 
@@ -342,13 +392,22 @@ hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const v
                       int64_t nt, int k, int32_t index_base, uint32_t *d_part, int32_t *d_out_idx,
                       int32_t *d_out_dist, uint8_t *d_keep, float ratio, hipStream_t stream)
 {
+    if (p.waves < 1 || p.waves > KNN_MAX_WAVES || p.n_splits > 65535 ||
+        (int64_t)p.rows_per_wave * p.waves < p.rows_per_split)
+        return hipErrorInvalidValue;
     dim3 grid((unsigned)p.q_blocks, (unsigned)p.n_splits);
-    knn_partial_kernel<1, 4><<<grid, KNN_BLOCK, 0, stream>>>(
-        (const uint4 *)d_query, (const uint4 *)d_train, nq, nt, p.rows_per_split, d_part);
+    if (p.lazy)
+        knn_partial_kernel<true><<<grid, p.waves * 64, 0, stream>>>(
+            (const uint4 *)d_query, (const uint4 *)d_train, nq, nt, p.rows_per_split,
+            p.rows_per_wave, d_part);
+    else
+        knn_partial_kernel<false><<<grid, p.waves * 64, 0, stream>>>(
+            (const uint4 *)d_query, (const uint4 *)d_train, nq, nt, p.rows_per_split,
+            p.rows_per_wave, d_part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
-    const unsigned mb = (unsigned)((nq + 255) / 256);
+    const unsigned mb = (unsigned)((nq + 63) / 64);
     knn_merge_kernel<<<mb, 256, 0, stream>>>(d_part, nq, p.n_splits, p.rows_per_split, k,
                                              index_base, d_out_idx, d_out_dist, d_keep, ratio);
     return hipGetLastError();

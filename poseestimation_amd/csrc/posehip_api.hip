@@ -139,8 +139,8 @@ ph_status knn_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t n
     if ((int64_t)base + nt - 1 > 0x7FFFFFFF)
         return fail(PH_ERR_TOO_LARGE, "train_index_base + nt exceeds the 32-bit index range");
     KnnPlan plan = knn_plan(nq, nt, g_ctx.n_cus);
-    if (plan.n_splits > 65535)
-        return fail(PH_ERR_TOO_LARGE, "train set needs %d splits (max 65535)", plan.n_splits);
+    if (plan.rows_per_split * (int64_t)plan.n_splits < nt)
+        return fail(PH_ERR_TOO_LARGE, "train set of %lld rows is too large for one call", (long long)nt);
     PH_HIP(part.reserve(plan.part_bytes));
     PH_HIP(knn_launch(plan, d_q, nq, d_t, nt, k, base, (uint32_t *)part.p, d_idx, d_dist, d_keep,
                       ratio, st));
