@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Hamming evals/s of the k=2 + ratio-test matcher on MI355X.
+
+Workload at every N (weak scaling): per rank, a step is one pass over a batch of
+`--frames-per-step` independent frames; each frame is ONE 10k x 10k
+`knnMatch(k=2)` + Lowe ratio test call (BASELINE.json configs[1]) against the
+same 10k-row train set, inputs resident in HBM.  Frames are independent, so
+ranks share nothing and no collective is on the data path.
+
+Prints one JSON line on rank 0 (see README/DESIGN for the fields).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--nq", type=int, default=10000)
+    ap.add_argument("--nt", type=int, default=10000)
+    ap.add_argument("--frames-per-step", type=int, default=16)
+    ap.add_argument("--ratio", type=float, default=0.75)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from poseestimation_amd import _lib
+    _lib.init(local_rank)
+    lib = _lib.load()
+
+    nq, nt, F = args.nq, args.nt, args.frames_per_step
+    # synthetic descriptors: iid uniform bytes (config "C2", seed 2 for the train
+    # set; every rank and frame has its own query seed)
+    t_host = np.random.default_rng(2).integers(0, 256, size=(nt, 32), dtype=np.uint8)
+    q_host = np.random.default_rng(1000 + rank).integers(0, 256, size=(F, nq, 32), dtype=np.uint8)
+    d_t = torch.from_numpy(t_host).to(dev)
+    d_q = torch.from_numpy(q_host).to(dev)
+    d_idx = torch.empty((F, nq, 2), dtype=torch.int32, device=dev)
+    d_dist = torch.empty((F, nq, 2), dtype=torch.int32, device=dev)
+    d_keep = torch.empty((F, nq), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    qp = [d_q[f].data_ptr() for f in range(F)]
+    ip = [d_idx[f].data_ptr() for f in range(F)]
+    dp = [d_dist[f].data_ptr() for f in range(F)]
+    kp = [d_keep[f].data_ptr() for f in range(F)]
+    tp = d_t.data_ptr()
+    ratio = C.c_float(args.ratio)
+    fn = lib.ph_knn_hamming256_dev
+
+    def step():
+        for f in range(F):
+            st = fn(qp[f], nq, tp, nt, 2, 0, ip[f], dp[f], kp[f], ratio, sptr)
+            if st != 0:
+                _lib.check(st)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    evals_per_step_all = float(nq) * nt * F * world
+    value = evals_per_step_all * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (distance kernel), measured live with
+        # HIP events on the launch stream, outside the timed region above
+        _lib.check(lib.ph_set_profiling(1))
+        ks, ms = [], []
+        a, b = C.c_float(0), C.c_float(0)
+        for r in range(60):
+            f = r % F
+            _lib.check(fn(qp[f], nq, tp, nt, 2, 0, ip[f], dp[f], kp[f], ratio, sptr))
+            _lib.check(lib.ph_knn_last_timing(C.byref(a), C.byref(b)))
+            if r >= 10:
+                ks.append(a.value)
+                ms.append(b.value)
+        _lib.check(lib.ph_set_profiling(0))
+        kernel_ms = float(np.mean(ks))
+        merge_ms = float(np.mean(ms))
+        peak_ops = C.c_double(0)
+        _lib.check(lib.ph_valu_popcount_peak(4000, C.byref(peak_ops)))
+        peak_evals = peak_ops.value / 16.0
+        achieved = float(nq) * nt / (kernel_ms * 1e-3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("knn_partial_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "valu",
+            "kernel": "knn_partial_kernel",
+            "achieved": achieved / 1e12,
+            "peak": peak_evals / 1e12,
+            "unit": "Teval/s",
+            "frac": achieved / peak_evals,
+            "traffic": traffic,
+            "work_per_launch": f"{nq}x{nt} Hamming-256 evals (16 VALU lane-ops each)",
+            "kernel_ms": kernel_ms,
+            "merge_kernel_ms": merge_ms,
+            "peak_source": "measured live: v_xor_b32+v_bcnt_u32_b32 mix, 8 waves/SIMD, /16",
+            "peak_spec": 256 * 64 * 2.4e9 / 16 / 1e12,
+            "hbm_algorithmic_GBps": 32.0 * (nq + nt) / (kernel_ms * 1e-3) / 1e9,
+        }
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            import oracle_bind as orc
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            threads = max(1, min(16, cores))
+            q0 = q_host[0]
+            reps, spent = 0, 0.0
+            ridx = rdist = None
+            while spent < args.cpu_seconds and reps < 50:
+                c0 = time.perf_counter()
+                ridx, rdist = orc.knn(q0, t_host, 2, threads=threads)
+                kept = orc.ratio_filter(ridx, rdist, args.ratio)
+                spent += time.perf_counter() - c0
+                reps += 1
+            cpu = {
+                "value": float(nq) * nt * reps / spent,
+                "unit": "Hamming evals/s",
+                "cores": threads,
+                "kind": "port",
+                "sample": f"{reps} x one {nq}x{nt} k=2 + ratio frame (oracle/bf_match.c, "
+                          f"{threads} pthreads)",
+            }
+            # the same frame on the GPU must agree bit for bit
+            g_idx = d_idx[0].cpu().numpy()
+            g_dist = d_dist[0].cpu().numpy()
+            g_keep = d_keep[0].cpu().numpy()
+            kept_q = np.array([m[0] for m in kept], dtype=np.int64)
+            ok = (np.array_equal(g_idx, ridx) and np.array_equal(g_dist, rdist)
+                  and np.array_equal(np.nonzero(g_keep)[0], kept_q))
+            cpu["gpu_matches_cpu"] = bool(ok)
+
+        out = {
+            "metric": "Hamming evals/sec (kNN k=2 + ratio test, 256-bit ORB descriptors)",
+            "value": value,
+            "unit": "Hamming evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (xor + popcount)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{nq}x{nt} ORB-descriptor kNN k=2 + ratio {args.ratio} per frame "
+                            f"(BASELINE configs[1]), {F} frames per step per GPU, one call per frame",
+                "nq": nq, "nt": nt, "k": 2, "frames_per_step": F,
+                "parallelism": f"frames x{world} (no collective)",
+            },
+            "us_per_frame": elapsed / args.steps / F * 1e6,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

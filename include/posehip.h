@@ -130,6 +130,21 @@ ph_status ph_match_crosscheck_hamming256_dev(const void *d_query, int64_t nq, co
                                              int64_t nt, int32_t *d_out_idx, int32_t *d_out_dist,
                                              void *stream);
 
+/* ---- measurement aids (no counterpart in the reference) -------------------- */
+
+/* With profiling on, every k-NN call records HIP events around its distance
+ * kernel and its merge kernel on the stream it uses; ph_knn_last_timing waits
+ * for the last such call and returns both durations in milliseconds. */
+ph_status ph_set_profiling(int enable);
+ph_status ph_knn_last_timing(float *distance_kernel_ms, float *merge_kernel_ms);
+
+/* Sustained VALU rate, in lane-operations per second, of the instruction pair
+ * the distance loop is made of (v_xor_b32 with a scalar operand + accumulating
+ * v_bcnt_u32_b32), 8 waves per SIMD on every CU, `iters` x 128 operations per
+ * lane.  One Hamming-256 evaluation is 16 such lane-operations, so the
+ * matcher's roofline is this figure / 16.  Blocks until measured. */
+ph_status ph_valu_popcount_peak(int iters, double *lane_ops_per_s);
+
 /* Blocks until everything enqueued on `stream` (NULL = library stream) is done. */
 ph_status ph_stream_synchronize(void *stream);
 

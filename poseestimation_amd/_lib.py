@@ -55,6 +55,9 @@ SIGNATURES = {
     "ph_match_crosscheck_hamming256_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "ph_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "ph_set_profiling": (C.c_int, [C.c_int]),
+    "ph_knn_last_timing": (C.c_int, [_f32p, _f32p]),
+    "ph_valu_popcount_peak": (C.c_int, [C.c_int, _f64p]),
 }
 
 _lib = None

@@ -28,7 +28,14 @@ KnnPlan knn_plan_custom(int64_t nq, int64_t nt, int waves, bool lazy, int64_t ma
 
 hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const void *d_train,
                       int64_t nt, int k, int32_t index_base, uint32_t *d_part, int32_t *d_out_idx,
-                      int32_t *d_out_dist, uint8_t *d_keep, float ratio, hipStream_t stream);
+                      int32_t *d_out_dist, uint8_t *d_keep, float ratio, hipStream_t stream,
+                      hipEvent_t *events = nullptr);
+
+// Sustained rate of the inner loop's instruction mix (v_xor_b32 with an SGPR
+// operand + accumulating v_bcnt_u32_b32) with 8 waves per SIMD on every CU:
+// the measured denominator of the matcher's roofline.  Blocks until done.
+hipError_t valu_popcount_peak(int n_cus, int iters, uint32_t *d_scratch, hipStream_t stream,
+                              double *lane_ops_per_s);
 
 hipError_t knn_merge_shards_launch(const int32_t *d_cand_idx, const int32_t *d_cand_dist,
                                    int n_shards, int64_t nq, int k, int32_t *d_out_idx,

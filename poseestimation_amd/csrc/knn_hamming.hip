@@ -390,12 +390,16 @@ KnnPlan knn_plan(int64_t nq, int64_t nt, int n_cus)
 
 hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const void *d_train,
                       int64_t nt, int k, int32_t index_base, uint32_t *d_part, int32_t *d_out_idx,
-                      int32_t *d_out_dist, uint8_t *d_keep, float ratio, hipStream_t stream)
+                      int32_t *d_out_dist, uint8_t *d_keep, float ratio, hipStream_t stream,
+                      hipEvent_t *events)
 {
     if (p.waves < 1 || p.waves > KNN_MAX_WAVES || p.n_splits > 65535 ||
         (int64_t)p.rows_per_wave * p.waves < p.rows_per_split)
         return hipErrorInvalidValue;
     dim3 grid((unsigned)p.q_blocks, (unsigned)p.n_splits);
+    hipError_t e;
+    if (events && (e = hipEventRecord(events[0], stream)) != hipSuccess)
+        return e;
     if (p.lazy)
         knn_partial_kernel<true><<<grid, p.waves * 64, 0, stream>>>(
             (const uint4 *)d_query, (const uint4 *)d_train, nq, nt, p.rows_per_split,
@@ -404,12 +408,76 @@ hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const v
         knn_partial_kernel<false><<<grid, p.waves * 64, 0, stream>>>(
             (const uint4 *)d_query, (const uint4 *)d_train, nq, nt, p.rows_per_split,
             p.rows_per_wave, d_part);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
+    if ((e = hipGetLastError()) != hipSuccess)
+        return e;
+    if (events && (e = hipEventRecord(events[1], stream)) != hipSuccess)
         return e;
     const unsigned mb = (unsigned)((nq + 63) / 64);
     knn_merge_kernel<<<mb, 256, 0, stream>>>(d_part, nq, p.n_splits, p.rows_per_split, k,
                                              index_base, d_out_idx, d_out_dist, d_keep, ratio);
+    if ((e = hipGetLastError()) != hipSuccess)
+        return e;
+    if (events && (e = hipEventRecord(events[2], stream)) != hipSuccess)
+        return e;
+    return hipSuccess;
+}
+
+// ---- VALU popcount peak --------------------------------------------------------
+// 8 independent chains per lane; one step = 8 x (v_xor_b32 with SGPR operand +
+// accumulating v_bcnt_u32_b32), the exact pair the distance loop issues.
+__global__ __launch_bounds__(256) void valu_peak_kernel(uint32_t *out, uint32_t s0, uint32_t s1,
+                                                        int iters)
+{
+    uint32_t q0 = threadIdx.x * 2654435761u, q1 = q0 ^ 0x9E3779B9u, q2 = q0 * 3, q3 = q0 * 5;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            uint32_t x0, x1, x2, x3, x4, x5, x6, x7;
+            asm volatile(
+                "v_xor_b32 %8, %16, %18\n v_xor_b32 %9, %17, %19\n v_xor_b32 %10, %16, %20\n"
+                "v_xor_b32 %11, %17, %21\n v_xor_b32 %12, %16, %19\n v_xor_b32 %13, %17, %18\n"
+                "v_xor_b32 %14, %16, %21\n v_xor_b32 %15, %17, %20\n"
+                "v_bcnt_u32_b32 %0, %8, %0\n v_bcnt_u32_b32 %1, %9, %1\n"
+                "v_bcnt_u32_b32 %2, %10, %2\n v_bcnt_u32_b32 %3, %11, %3\n"
+                "v_bcnt_u32_b32 %4, %12, %4\n v_bcnt_u32_b32 %5, %13, %5\n"
+                "v_bcnt_u32_b32 %6, %14, %6\n v_bcnt_u32_b32 %7, %15, %7\n"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+                  "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6),
+                  "=&v"(x7)
+                : "s"(s0), "s"(s1), "v"(q0), "v"(q1), "v"(q2), "v"(q3));
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+hipError_t valu_popcount_peak(int n_cus, int iters, uint32_t *d_scratch, hipStream_t stream,
+                              double *lane_ops_per_s)
+{
+    const int blocks = n_cus * 8; // 8 workgroups x 4 waves per CU = 8 waves per SIMD
+    hipEvent_t e0, e1;
+    hipError_t e;
+    if ((e = hipEventCreate(&e0)) != hipSuccess)
+        return e;
+    if ((e = hipEventCreate(&e1)) != hipSuccess)
+        return e;
+    float best = 0.f;
+    for (int r = 0; r < 4; r++) { // first pass warms up
+        (void)hipEventRecord(e0, stream);
+        valu_peak_kernel<<<blocks, 256, 0, stream>>>(d_scratch, 0x12345678u, 0x9abcdef0u, iters);
+        (void)hipEventRecord(e1, stream);
+        if ((e = hipEventSynchronize(e1)) != hipSuccess)
+            break;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && (best == 0.f || ms < best))
+            best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess)
+        return e;
+    *lane_ops_per_s = (double)blocks * 256.0 * (double)iters * 8 * 16 / (best * 1e-3);
     return hipGetLastError();
 }
 

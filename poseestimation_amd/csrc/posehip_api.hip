@@ -78,6 +78,9 @@ struct Context {
     DevBuf tmp_i;  // cross-check per-train nearest query index
     DevBuf tmp_d;  // cross-check per-train nearest query distance
     DevBuf in_q, in_t, out_i, out_d, out_k; // staging for the host entry points
+    bool profiling = false;                 // record events around the distance kernel
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool ev_valid = false;
 };
 
 Context g_ctx;
@@ -142,8 +145,10 @@ ph_status knn_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t n
     if (plan.rows_per_split * (int64_t)plan.n_splits < nt)
         return fail(PH_ERR_TOO_LARGE, "train set of %lld rows is too large for one call", (long long)nt);
     PH_HIP(part.reserve(plan.part_bytes));
+    hipEvent_t *ev = g_ctx.profiling ? g_ctx.ev : nullptr;
     PH_HIP(knn_launch(plan, d_q, nq, d_t, nt, k, base, (uint32_t *)part.p, d_idx, d_dist, d_keep,
-                      ratio, st));
+                      ratio, st, ev));
+    g_ctx.ev_valid = ev != nullptr;
     return PH_OK;
 }
 
@@ -243,6 +248,9 @@ void ph_shutdown(void)
     for (DevBuf *b : all)
         b->release();
     (void)hipStreamDestroy(g_ctx.stream);
+    for (hipEvent_t e : g_ctx.ev)
+        if (e)
+            (void)hipEventDestroy(e);
     g_ctx = Context();
 }
 
@@ -257,6 +265,50 @@ ph_status ph_stream_synchronize(void *stream)
     if (s != PH_OK)
         return s;
     PH_HIP(hipStreamSynchronize(pick_stream(stream)));
+    return PH_OK;
+}
+
+ph_status ph_set_profiling(int enable)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (enable && !g_ctx.ev[0])
+        for (hipEvent_t &e : g_ctx.ev)
+            PH_HIP(hipEventCreate(&e));
+    g_ctx.profiling = enable != 0;
+    g_ctx.ev_valid = false;
+    return PH_OK;
+}
+
+ph_status ph_knn_last_timing(float *distance_kernel_ms, float *merge_kernel_ms)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (!g_ctx.ev_valid)
+        return fail(PH_ERR_INVALID_ARG, "no profiled k-NN call (ph_set_profiling(1) first)");
+    PH_HIP(hipEventSynchronize(g_ctx.ev[2]));
+    if (distance_kernel_ms)
+        PH_HIP(hipEventElapsedTime(distance_kernel_ms, g_ctx.ev[0], g_ctx.ev[1]));
+    if (merge_kernel_ms)
+        PH_HIP(hipEventElapsedTime(merge_kernel_ms, g_ctx.ev[1], g_ctx.ev[2]));
+    return PH_OK;
+}
+
+ph_status ph_valu_popcount_peak(int iters, double *lane_ops_per_s)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (iters < 1 || !lane_ops_per_s)
+        return fail(PH_ERR_INVALID_ARG, "iters must be >= 1 and the output non-null");
+    PH_HIP(g_ctx.tmp_i.reserve((size_t)g_ctx.n_cus * 8 * 256 * sizeof(uint32_t)));
+    PH_HIP(valu_popcount_peak(g_ctx.n_cus, iters, (uint32_t *)g_ctx.tmp_i.p, g_ctx.stream,
+                              lane_ops_per_s));
     return PH_OK;
 }
 

@@ -32,7 +32,11 @@ def load():
     stale = (not os.path.exists(LIB_PATH)
              or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
     if stale:
-        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+        try:
+            subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+        except (OSError, subprocess.CalledProcessError):
+            if not os.path.exists(LIB_PATH):
+                raise
     lib = C.CDLL(LIB_PATH)
     lib.orc_knn_hamming256.restype = C.c_int
     lib.orc_knn_hamming256.argtypes = [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int, C.c_size_t,
