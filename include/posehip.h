@@ -130,6 +130,47 @@ ph_status ph_match_crosscheck_hamming256_dev(const void *d_query, int64_t nq, co
                                              int64_t nt, int32_t *d_out_idx, int32_t *d_out_dist,
                                              void *stream);
 
+/* ---- RANSAC-EPnP pose ------------------------------------------------------- */
+/* Replaces cv::solvePnPRansac(obj, img, K, noArray(), rvec, tvec, false,
+ * iterationsCount, reprojectionError, confidence, inliers, SOLVEPNP_EPNP), the
+ * call the reference's EPnP branch makes where this checkout has the TODO at
+ * src/cereal_box.cpp:292-295 (docs/index.md:75,120).  Zero lens distortion (the
+ * reference renders with an ideal pinhole, src/cereal_box.cpp:222).
+ *
+ * obj: n x 3 float model points, img: n x 2 float pixels, K: row-major 3 x 3.
+ * rng_state seeds OpenCV's multiply-with-carry cv::RNG; OpenCV itself always
+ * uses 0xFFFFFFFFFFFFFFFF.  *found = 1 iff a pose was found (OpenCV's return
+ * value); rvec/tvec then hold the EPnP refit over all inliers, inliers (n
+ * entries, may be NULL) their ascending row indices.  iterations_run (may be
+ * NULL) = RANSAC iterations consumed after the adaptive budget cut.  n < 5 is
+ * PH_ERR_INVALID_ARG (OpenCV asserts n >= 4 and uses P3P at n == 4, which is
+ * outside this path). */
+ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, const double *K,
+                                  int iterations_count, float reproj_err, double confidence,
+                                  uint64_t rng_state, double *rvec, double *tvec,
+                                  int32_t *inliers, int *n_inliers, int *found,
+                                  int *iterations_run);
+
+/* cv::solvePnP(obj, img, K, noArray(), rvec, tvec, false, SOLVEPNP_EPNP) on
+ * n >= 4 correspondences (the per-sample kernel and the final refit of the call
+ * above). */
+ph_status ph_solvepnp_epnp(const float *obj, const float *img, int n, const double *K,
+                           double *rvec, double *tvec);
+
+/* The first n_subsets 5-point samples RANSACPointSetRegistrator::run draws from
+ * n_points correspondences with cv::RNG state rng_state: out[5*s .. 5*s+5).
+ * Host-only. */
+ph_status ph_ransac_subsets(uint64_t rng_state, int n_points, int n_subsets, int32_t *out);
+
+/* Hypothesis generation + scoring on device buffers: for each of n_hyp 5-point
+ * samples (d_subsets, row indices) solve EPnP -> d_models[6h..6h+6) = rvec|tvec
+ * (double) and count the inliers of that model over all n correspondences ->
+ * d_counts[h].  K is a host pointer.  Enqueues on `stream` and returns. */
+ph_status ph_ransac_epnp_hypotheses_dev(const float *d_obj, const float *d_img, int n,
+                                        const double *K, const int32_t *d_subsets, int n_hyp,
+                                        float reproj_err, double *d_models, int32_t *d_counts,
+                                        void *stream);
+
 /* ---- measurement aids (no counterpart in the reference) -------------------- */
 
 /* With profiling on, every k-NN call records HIP events around its distance

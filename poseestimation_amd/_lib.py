@@ -55,6 +55,14 @@ SIGNATURES = {
     "ph_match_crosscheck_hamming256_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "ph_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "ph_solvepnp_ransac_epnp": (C.c_int, [_f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_float,
+                                          C.c_double, C.c_uint64, _f64p, _f64p, _i32p, _intp,
+                                          _intp, _intp]),
+    "ph_solvepnp_epnp": (C.c_int, [_f32p, _f32p, C.c_int, _f64p, _f64p, _f64p]),
+    "ph_ransac_subsets": (C.c_int, [C.c_uint64, C.c_int, C.c_int, _i32p]),
+    "ph_ransac_epnp_hypotheses_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _f64p,
+                                                C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]),
     "ph_set_profiling": (C.c_int, [C.c_int]),
     "ph_knn_last_timing": (C.c_int, [_f32p, _f32p]),
     "ph_valu_popcount_peak": (C.c_int, [C.c_int, _f64p]),
@@ -68,6 +76,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own HIP runtime; when both live in one process the runtime
+    # must be loaded once, so let torch load it first if torch is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C poseestimation_amd/csrc` "

@@ -5,11 +5,14 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
+#include <cfloat>
 #include <cstring>
 #include <mutex>
 #include <vector>
 
 #include "knn_hamming.h"
+#include "ransac_epnp.h"
 #include "posehip.h"
 
 namespace {
@@ -78,6 +81,7 @@ struct Context {
     DevBuf tmp_i;  // cross-check per-train nearest query index
     DevBuf tmp_d;  // cross-check per-train nearest query distance
     DevBuf in_q, in_t, out_i, out_d, out_k; // staging for the host entry points
+    DevBuf pnp_obj, pnp_img, pnp_sub, pnp_models, pnp_counts, pnp_mask, pnp_idx; // RANSAC-EPnP
     bool profiling = false;                 // record events around the distance kernel
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -204,6 +208,69 @@ ph_status check_host_args(const uint8_t *q, int nq, size_t q_step, const uint8_t
     return PH_OK;
 }
 
+// ---- RANSAC host logic ------------------------------------------------------------
+// cv::RNG: multiply-with-carry, state = lo32 * 4164903690 + hi32.
+struct CvRng {
+    uint64_t state;
+    explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffu) {}
+    uint32_t next()
+    {
+        state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32);
+        return (uint32_t)state;
+    }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (uint32_t)(b - a) + a); }
+};
+
+// RANSACPointSetRegistrator::getSubset for the PnP callback (checkSubset always
+// accepts): five distinct row indices, redrawing a slot while it repeats an
+// earlier one.  The draws do not depend on any model, so the whole sequence of
+// subsets can be generated before a single hypothesis is solved.
+void draw_subsets(uint64_t rng_state, int count, int n_subsets, int32_t *out)
+{
+    CvRng rng(rng_state);
+    for (int s = 0; s < n_subsets; s++) {
+        int32_t *idx = out + (size_t)s * 5;
+        for (int i = 0; i < 5; i++) {
+            int v;
+            bool dup;
+            do {
+                v = rng.uniform(0, count);
+                dup = false;
+                for (int j = 0; j < i; j++)
+                    dup |= idx[j] == v;
+            } while (dup);
+            idx[i] = v;
+        }
+    }
+}
+
+// RANSACUpdateNumIters.
+int update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = std::max(p, 0.);
+    p = std::min(p, 1.);
+    ep = std::max(ep, 0.);
+    ep = std::min(ep, 1.);
+    double num = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, model_points);
+    if (denom < DBL_MIN)
+        return 0;
+    num = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
+}
+
+ph_status check_pnp_args(const void *obj, const void *img, int n, const double *K)
+{
+    if (n < 0 || (n > 0 && (!obj || !img)) || !K)
+        return fail(PH_ERR_INVALID_ARG, "bad correspondence arrays or camera matrix");
+    if (!(K[0] != 0.0) || !(K[4] != 0.0))
+        return fail(PH_ERR_INVALID_ARG, "camera matrix has a zero focal length");
+    return PH_OK;
+}
+
+CameraK camera_of(const double *K) { return CameraK{K[0], K[4], K[2], K[5]}; }
+
 } // namespace
 
 extern "C" {
@@ -243,8 +310,11 @@ void ph_shutdown(void)
         return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipStreamSynchronize(g_ctx.stream);
-    DevBuf *all[] = {&g_ctx.part, &g_ctx.part2, &g_ctx.best, &g_ctx.tmp_i, &g_ctx.tmp_d,
-                     &g_ctx.in_q, &g_ctx.in_t,  &g_ctx.out_i, &g_ctx.out_d, &g_ctx.out_k};
+    DevBuf *all[] = {&g_ctx.part,      &g_ctx.part2,      &g_ctx.best,       &g_ctx.tmp_i,
+                     &g_ctx.tmp_d,     &g_ctx.in_q,       &g_ctx.in_t,       &g_ctx.out_i,
+                     &g_ctx.out_d,     &g_ctx.out_k,      &g_ctx.pnp_obj,    &g_ctx.pnp_img,
+                     &g_ctx.pnp_sub,   &g_ctx.pnp_models, &g_ctx.pnp_counts, &g_ctx.pnp_mask,
+                     &g_ctx.pnp_idx};
     for (DevBuf *b : all)
         b->release();
     (void)hipStreamDestroy(g_ctx.stream);
@@ -541,6 +611,195 @@ ph_status ph_knn2_ratio_hamming256(const uint8_t *query, int nq, size_t q_step,
         n++;
     }
     *n_out = n;
+    return PH_OK;
+}
+
+ph_status ph_ransac_subsets(uint64_t rng_state, int n_points, int n_subsets, int32_t *out)
+{
+    if (n_points < 5 || n_subsets < 0 || (n_subsets > 0 && !out))
+        return fail(PH_ERR_INVALID_ARG, "need >= 5 points and a non-null output");
+    draw_subsets(rng_state, n_points, n_subsets, out);
+    return PH_OK;
+}
+
+ph_status ph_ransac_epnp_hypotheses_dev(const float *d_obj, const float *d_img, int n,
+                                        const double *K, const int32_t *d_subsets, int n_hyp,
+                                        float reproj_err, double *d_models, int32_t *d_counts,
+                                        void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if ((s = check_pnp_args(d_obj, d_img, n, K)) != PH_OK)
+        return s;
+    if (n < 5 || n_hyp < 0 || (n_hyp > 0 && (!d_subsets || !d_models || !d_counts)))
+        return fail(PH_ERR_INVALID_ARG, "need >= 5 correspondences and non-null buffers");
+    const double thr = reproj_err;
+    PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, camera_of(K), d_subsets, n_hyp,
+                                    (float)(thr * thr), d_models, d_counts, pick_stream(stream)));
+    return PH_OK;
+}
+
+ph_status ph_solvepnp_epnp(const float *obj, const float *img, int n, const double *K,
+                           double *rvec, double *tvec)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if ((s = check_pnp_args(obj, img, n, K)) != PH_OK)
+        return s;
+    if (n < 4 || !rvec || !tvec)
+        return fail(PH_ERR_INVALID_ARG, "EPnP needs >= 4 correspondences and output pointers");
+    hipStream_t st = g_ctx.stream;
+    PH_HIP(g_ctx.pnp_obj.reserve((size_t)n * 12));
+    PH_HIP(g_ctx.pnp_img.reserve((size_t)n * 8));
+    PH_HIP(g_ctx.pnp_models.reserve(6 * sizeof(double)));
+    PH_HIP(hipMemcpyAsync(g_ctx.pnp_obj.p, obj, (size_t)n * 12, hipMemcpyHostToDevice, st));
+    PH_HIP(hipMemcpyAsync(g_ctx.pnp_img.p, img, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    PH_HIP(epnp_solve_launch((const float *)g_ctx.pnp_obj.p, (const float *)g_ctx.pnp_img.p,
+                             nullptr, n, camera_of(K), (double *)g_ctx.pnp_models.p, st));
+    double m[6];
+    PH_HIP(hipMemcpyAsync(m, g_ctx.pnp_models.p, sizeof(m), hipMemcpyDeviceToHost, st));
+    PH_HIP(hipStreamSynchronize(st));
+    memcpy(rvec, m, 3 * sizeof(double));
+    memcpy(tvec, m + 3, 3 * sizeof(double));
+    return PH_OK;
+}
+
+ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, const double *K,
+                                  int iterations_count, float reproj_err, double confidence,
+                                  uint64_t rng_state, double *rvec, double *tvec,
+                                  int32_t *inliers, int *n_inliers, int *found,
+                                  int *iterations_run)
+{
+    if (found)
+        *found = 0;
+    if (n_inliers)
+        *n_inliers = 0;
+    if (iterations_run)
+        *iterations_run = 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if ((s = check_pnp_args(obj, img, n, K)) != PH_OK)
+        return s;
+    if (!rvec || !tvec || !found)
+        return fail(PH_ERR_INVALID_ARG, "rvec, tvec and found must be non-null");
+    if (!(confidence > 0 && confidence < 1))
+        return fail(PH_ERR_INVALID_ARG, "confidence must lie in (0, 1)"); // CV_Assert in run()
+    if (n < 5)
+        // OpenCV asserts npoints >= 4 and switches to P3P at exactly 4: not this path
+        return fail(PH_ERR_INVALID_ARG, "RANSAC-EPnP needs >= 5 correspondences (got %d)", n);
+    const int model_points = 5;
+    const CameraK cam = camera_of(K);
+    const double thr = reproj_err;
+    const float thr2 = (float)(thr * thr);
+    hipStream_t st = g_ctx.stream;
+    PH_HIP(g_ctx.pnp_obj.reserve((size_t)n * 12));
+    PH_HIP(g_ctx.pnp_img.reserve((size_t)n * 8));
+    PH_HIP(hipMemcpyAsync(g_ctx.pnp_obj.p, obj, (size_t)n * 12, hipMemcpyHostToDevice, st));
+    PH_HIP(hipMemcpyAsync(g_ctx.pnp_img.p, img, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    const float *d_obj = (const float *)g_ctx.pnp_obj.p, *d_img = (const float *)g_ctx.pnp_img.p;
+    PH_HIP(g_ctx.pnp_models.reserve(6 * sizeof(double)));
+
+    if (n == model_points) { // run(): count == modelPoints -> one solve, every point an inlier
+        PH_HIP(epnp_solve_launch(d_obj, d_img, nullptr, n, cam, (double *)g_ctx.pnp_models.p, st));
+        double m[6];
+        PH_HIP(hipMemcpyAsync(m, g_ctx.pnp_models.p, sizeof(m), hipMemcpyDeviceToHost, st));
+        PH_HIP(hipStreamSynchronize(st));
+        memcpy(rvec, m, 3 * sizeof(double));
+        memcpy(tvec, m + 3, 3 * sizeof(double));
+        if (inliers)
+            for (int i = 0; i < n; i++)
+                inliers[i] = i;
+        if (n_inliers)
+            *n_inliers = n;
+        *found = 1;
+        return PH_OK;
+    }
+
+    // The subset sequence is model-independent, so all hypotheses of the budget
+    // are solved and scored in parallel, in chunks; OpenCV's sequential rule
+    // (strictly larger count wins, budget shrinks on every win) is then replayed
+    // over the counts, and chunks beyond the shrunken budget are never launched.
+    int niters = std::max(iterations_count, 1);
+    const int total = niters;
+    std::vector<int32_t> subsets((size_t)total * 5);
+    draw_subsets(rng_state, n, total, subsets.data());
+    PH_HIP(g_ctx.pnp_sub.reserve(subsets.size() * sizeof(int32_t)));
+    PH_HIP(hipMemcpyAsync(g_ctx.pnp_sub.p, subsets.data(), subsets.size() * sizeof(int32_t),
+                          hipMemcpyHostToDevice, st));
+    const int chunk = 4096;
+    PH_HIP(g_ctx.pnp_models.reserve((size_t)std::min(total, chunk) * 6 * sizeof(double) + 64));
+    PH_HIP(g_ctx.pnp_counts.reserve((size_t)std::min(total, chunk) * sizeof(int32_t)));
+    std::vector<double> models((size_t)std::min(total, chunk) * 6);
+    std::vector<int32_t> counts((size_t)std::min(total, chunk));
+    int max_good = 0, iter = 0;
+    double best[6] = {0, 0, 0, 0, 0, 0};
+    for (int base = 0; base < total && base < niters; base += chunk) {
+        const int m = std::min(chunk, total - base);
+        PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, cam,
+                                        (const int32_t *)g_ctx.pnp_sub.p + (size_t)base * 5, m,
+                                        thr2, (double *)g_ctx.pnp_models.p,
+                                        (int32_t *)g_ctx.pnp_counts.p, st));
+        PH_HIP(hipMemcpyAsync(models.data(), g_ctx.pnp_models.p, (size_t)m * 6 * sizeof(double),
+                              hipMemcpyDeviceToHost, st));
+        PH_HIP(hipMemcpyAsync(counts.data(), g_ctx.pnp_counts.p, (size_t)m * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, st));
+        PH_HIP(hipStreamSynchronize(st));
+        for (iter = base; iter < base + m && iter < niters; iter++) {
+            const int good = counts[iter - base];
+            if (good > std::max(max_good, model_points - 1)) {
+                memcpy(best, &models[(size_t)(iter - base) * 6], sizeof(best));
+                max_good = good;
+                niters = update_num_iters(confidence, (double)(n - good) / n, model_points, niters);
+            }
+        }
+    }
+    if (iterations_run)
+        *iterations_run = iter;
+    if (max_good <= 0) {
+        *found = 0;
+        return PH_OK;
+    }
+    // inlier mask of the best model, then one EPnP solve over its inliers
+    PH_HIP(g_ctx.pnp_mask.reserve((size_t)n));
+    PH_HIP(hipMemcpyAsync(g_ctx.pnp_models.p, best, sizeof(best), hipMemcpyHostToDevice, st));
+    PH_HIP(inlier_mask_launch(d_obj, d_img, n, cam, (const double *)g_ctx.pnp_models.p, thr2,
+                              (uint8_t *)g_ctx.pnp_mask.p, st));
+    std::vector<uint8_t> mask((size_t)n);
+    PH_HIP(hipMemcpyAsync(mask.data(), g_ctx.pnp_mask.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipStreamSynchronize(st));
+    std::vector<int32_t> idx;
+    idx.reserve((size_t)max_good);
+    for (int i = 0; i < n; i++)
+        if (mask[i])
+            idx.push_back(i);
+    const int k = (int)idx.size();
+    if (k < 4) { // cannot happen with max_good >= 5; solvePnP would throw and RANSAC report failure
+        memcpy(rvec, best, 3 * sizeof(double));
+        memcpy(tvec, best + 3, 3 * sizeof(double));
+        *found = 0;
+        return PH_OK;
+    }
+    PH_HIP(g_ctx.pnp_idx.reserve((size_t)k * sizeof(int32_t)));
+    PH_HIP(hipMemcpyAsync(g_ctx.pnp_idx.p, idx.data(), (size_t)k * sizeof(int32_t),
+                          hipMemcpyHostToDevice, st));
+    PH_HIP(epnp_solve_launch(d_obj, d_img, (const int32_t *)g_ctx.pnp_idx.p, k, cam,
+                             (double *)g_ctx.pnp_models.p, st));
+    double m6[6];
+    PH_HIP(hipMemcpyAsync(m6, g_ctx.pnp_models.p, sizeof(m6), hipMemcpyDeviceToHost, st));
+    PH_HIP(hipStreamSynchronize(st));
+    memcpy(rvec, m6, 3 * sizeof(double));
+    memcpy(tvec, m6 + 3, 3 * sizeof(double));
+    if (inliers)
+        memcpy(inliers, idx.data(), (size_t)k * sizeof(int32_t));
+    if (n_inliers)
+        *n_inliers = k;
+    *found = 1;
     return PH_OK;
 }
 

@@ -1,0 +1,27 @@
+// Internal interface between the C ABI (posehip_api.hip) and the RANSAC-EPnP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace posehip {
+
+struct CameraK {
+    double fx, fy, cx, cy;
+};
+
+// n_hyp hypotheses: EPnP on rows d_subsets[5h..5h+5) -> d_models[6h..] = rvec|tvec and the
+// inlier count over all n rows -> d_counts[h].  thr2 = (float)(reprojectionError^2).
+hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int n, CameraK K,
+                                    const int32_t *d_subsets, int n_hyp, float thr2,
+                                    double *d_models, int32_t *d_counts, hipStream_t stream);
+
+// One byte per row: 1 iff the row is an inlier of d_model (rvec|tvec).
+hipError_t inlier_mask_launch(const float *d_obj, const float *d_img, int n, CameraK K,
+                              const double *d_model, float thr2, uint8_t *d_mask,
+                              hipStream_t stream);
+
+// EPnP on rows d_idx[0..n) (d_idx may be null: rows 0..n) -> d_model = rvec|tvec.
+hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,
+                             CameraK K, double *d_model, hipStream_t stream);
+
+} // namespace posehip

@@ -1,0 +1,908 @@
+// RANSAC-EPnP hypothesis generation and inlier scoring for gfx950 (MI355X).
+//
+// Arithmetic replaced: cv::solvePnPRansac(..., SOLVEPNP_EPNP), the pose stage of
+// the reference's EPnP branch (reference docs/index.md:75,120; TODO at
+// src/cereal_box.cpp:292-295).  Per RANSAC iteration OpenCV solves EPnP on a
+// 5-point sample (four control points, 12 x 12 null-space problem by one-sided
+// Jacobi SVD, three beta initialisations each refined by 5 Gauss-Newton steps,
+// pose from the best one), converts R to a rotation vector, and counts the
+// points whose float squared reprojection error is <= threshold^2.
+//
+// Mapping.  One hypothesis per wavefront.  The EPnP solve is a short, strictly
+// sequential fp64 computation; it runs on lane 0 with its small matrices in the
+// wave's LDS block, every operation in the same order as a plain sequential
+// statement of the algorithm (built with -ffp-contract=off) so that poses agree
+// with a CPU statement to the last bits.  Per-point quantities (barycentric
+// coordinates, camera-frame points) are recomputed where they are used instead
+// of stored, so the same routine refits on any number of inliers in O(1)
+// memory.  Scoring then uses all 64 lanes: lanes stride over the
+// correspondences and the inlier count is reduced with ballot + popcount.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "ransac_epnp.h"
+
+namespace posehip {
+
+namespace {
+
+// ---- cv::RNG (multiply-with-carry), used by the SVD's zero-row completion ----
+struct Rng {
+    uint64_t state;
+    __device__ uint32_t next()
+    {
+        state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32);
+        return (uint32_t)state;
+    }
+};
+
+// sqrt(x*x + y*y) by N. Borges' corrected algorithm (one sqrt plus one
+// correction step on the larger/smaller operands), the method current C
+// libraries use for hypot; it returns the correctly rounded value in practice,
+// so the Jacobi rotations below round exactly like a host statement that calls
+// the C library's hypot.
+__device__ inline double hypot_kernel(double ax, double ay)
+{
+    double t1, t2;
+    double h = sqrt(ax * ax + ay * ay);
+    if (h <= 2.0 * ay) {
+        const double delta = h - ay;
+        t1 = ax * (2.0 * delta - ax);
+        t2 = (delta - 2.0 * (ax - ay)) * delta;
+    } else {
+        const double delta = h - ax;
+        t1 = 2.0 * delta * (ax - 2.0 * ay);
+        t2 = (4.0 * delta - ay) * ay + delta * delta;
+    }
+    h -= (t1 + t2) / (2.0 * h);
+    return h;
+}
+
+__device__ double hypot_cr(double x, double y)
+{
+    const double SCALE = 0x1p-600, LARGE_VAL = 0x1p+511, TINY_VAL = 0x1p-459, EPS = 0x1p-54;
+    if (!isfinite(x) || !isfinite(y)) {
+        if (isinf(x) || isinf(y))
+            return INFINITY;
+        return x + y;
+    }
+    x = fabs(x);
+    y = fabs(y);
+    const double ax = x < y ? y : x, ay = x < y ? x : y;
+    if (ax > LARGE_VAL) {
+        if (ay <= ax * EPS)
+            return ax + ay;
+        return hypot_kernel(ax * SCALE, ay * SCALE) / SCALE;
+    }
+    if (ay < TINY_VAL) {
+        if (ax >= ay / EPS)
+            return ax + ay;
+        return hypot_kernel(ax / SCALE, ay / SCALE) * SCALE;
+    }
+    if (ax >= ay / EPS)
+        return ax + ay;
+    return hypot_kernel(ax, ay);
+}
+
+// One-sided Jacobi SVD on the n rows of At (length m each); rotations
+// accumulate in Vt (n x n).  On exit the rows of At are the left singular
+// vectors, W descending.  Same sweep order, thresholds and zero-row completion
+// as OpenCV's JacobiSVDImpl_<double>.  W is an n-entry work array.
+__device__ void jacobi_svd(double *At, int astep, double *W, double *Vt, int vstep, int m, int n)
+{
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+    const int max_iter = m > 30 ? m : 30;
+    double c, s;
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) {
+            const double t = At[i * astep + k];
+            sd += t * t;
+        }
+        W[i] = sd;
+        for (int k = 0; k < n; k++)
+            Vt[i * vstep + k] = 0;
+        Vt[i * vstep + i] = 1;
+    }
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                double *Ai = At + i * astep, *Aj = At + j * astep;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < m; k++)
+                    p += Ai[k] * Aj[k];
+                if (fabs(p) <= eps * sqrt(a * b))
+                    continue;
+                p *= 2;
+                const double beta = a - b, gamma = hypot_cr(p, beta);
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+                for (int k = 0; k < m; k++) {
+                    const double t0 = c * Ai[k] + s * Aj[k];
+                    const double t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0;
+                    Aj[k] = t1;
+                    a += t0 * t0;
+                    b += t1 * t1;
+                }
+                W[i] = a;
+                W[j] = b;
+                changed = true;
+                double *Vi = Vt + i * vstep, *Vj = Vt + j * vstep;
+                for (int k = 0; k < n; k++) {
+                    const double t0 = c * Vi[k] + s * Vj[k];
+                    const double t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0;
+                    Vj[k] = t1;
+                }
+            }
+        if (!changed)
+            break;
+    }
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) {
+            const double t = At[i * astep + k];
+            sd += t * t;
+        }
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++)
+            if (W[j] < W[k])
+                j = k;
+        if (i != j) {
+            double t = W[i];
+            W[i] = W[j];
+            W[j] = t;
+            for (int k = 0; k < m; k++) {
+                t = At[i * astep + k];
+                At[i * astep + k] = At[j * astep + k];
+                At[j * astep + k] = t;
+            }
+            for (int k = 0; k < n; k++) {
+                t = Vt[i * vstep + k];
+                Vt[i * vstep + k] = Vt[j * vstep + k];
+                Vt[j * vstep + k] = t;
+            }
+        }
+    }
+    Rng rng{0x12345678};
+    for (int i = 0; i < n; i++) {
+        double sd = W[i];
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const double val0 = 1. / m;
+            for (int k = 0; k < m; k++)
+                At[i * astep + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+            for (int iter = 0; iter < 2; iter++)
+                for (int j = 0; j < i; j++) {
+                    sd = 0;
+                    for (int k = 0; k < m; k++)
+                        sd += At[i * astep + k] * At[j * astep + k];
+                    double asum = 0;
+                    for (int k = 0; k < m; k++) {
+                        const double t = At[i * astep + k] - sd * At[j * astep + k];
+                        At[i * astep + k] = t;
+                        asum += fabs(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+                    for (int k = 0; k < m; k++)
+                        At[i * astep + k] *= asum;
+                }
+            sd = 0;
+            for (int k = 0; k < m; k++) {
+                const double t = At[i * astep + k];
+                sd += t * t;
+            }
+            sd = sqrt(sd);
+        }
+        s = sd > minval ? 1 / sd : 0.;
+        for (int k = 0; k < m; k++)
+            At[i * astep + k] *= s;
+    }
+}
+
+// Per-wave LDS block.
+struct EpnpLds {
+    double ut[144];   // 12 x 12: MtM, then its left singular vectors (rows)
+    double vt[144];
+    double w[12];
+    double sa[36];    // small SVDs: At (up to 5 x 6)
+    double sv[25];
+    double sw[8];
+    double l[60];     // L_6x10
+    double ga[24];    // Gauss-Newton A (6 x 4)
+    double out[16];   // rvec(3) tvec(3) R'(9) handed to the scoring lanes
+};
+
+// SVD of a square matrix given TRANSPOSED in S.sa (n x n, n <= 3 here): after
+// the call S.sa holds Ut (rows = left singular vectors), S.sv holds Vt.
+__device__ void svd_small_square(EpnpLds &S, int n) { jacobi_svd(S.sa, n, S.sw, S.sv, n, n, n); }
+
+// cv::solve(A, b, x, DECOMP_SVD), A m x n row-major in registers/LDS via getter.
+__device__ void solve_svd(EpnpLds &S, const double *A, int m, int n, const double *b, double *x)
+{
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++)
+            S.sa[i * m + j] = A[j * n + i];
+    jacobi_svd(S.sa, m, S.sw, S.sv, n, m, n);
+    double threshold = 0;
+    for (int i = 0; i < n; i++) {
+        x[i] = 0;
+        threshold += S.sw[i];
+    }
+    threshold *= DBL_EPSILON * 2;
+    for (int i = 0; i < n; i++) {
+        double wi = S.sw[i];
+        if (fabs(wi) <= threshold)
+            continue;
+        wi = 1 / wi;
+        double s = 0;
+        for (int j = 0; j < m; j++)
+            s += S.sa[i * m + j] * b[j];
+        s *= wi;
+        for (int j = 0; j < n; j++)
+            x[j] = x[j] + s * S.sv[i * n + j];
+    }
+}
+
+__device__ inline double dot3(const double *a, const double *b)
+{
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+__device__ inline double dist2(const double *p1, const double *p2)
+{
+    return (p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]) +
+           (p1[2] - p2[2]) * (p1[2] - p2[2]);
+}
+
+// Correspondences of one solve: rows idx[0..n) of obj/img (idx == nullptr: rows 0..n).
+struct Points {
+    const float *obj;
+    const float *img;
+    const int32_t *idx;
+    int n;
+    double fu, fv, uc, vc, ifx, ify;
+    __device__ void world(int i, double *pw) const
+    {
+        const int64_t r = idx ? idx[i] : i;
+        pw[0] = obj[3 * r];
+        pw[1] = obj[3 * r + 1];
+        pw[2] = obj[3 * r + 2];
+    }
+    // undistortPoints with zero distortion stores (u - cx)/fx as float; EPnP maps it back.
+    __device__ void pixel(int i, double &u, double &v) const
+    {
+        const int64_t r = idx ? idx[i] : i;
+        const float xn = (float)(((double)img[2 * r] - uc) * ifx);
+        const float yn = (float)(((double)img[2 * r + 1] - vc) * ify);
+        u = xn * fu + uc;
+        v = yn * fv + vc;
+    }
+};
+
+struct EpnpState {
+    double cws[4][3];
+    double ci[9]; // inverse of the control-point basis
+    double ccs[4][3];
+    bool flip;    // solve_for_sign decision of the current candidate
+};
+
+__device__ inline void alphas_of(const EpnpState &e, const double *pi, double *a)
+{
+    for (int j = 0; j < 3; j++)
+        a[1 + j] = e.ci[3 * j] * (pi[0] - e.cws[0][0]) + e.ci[3 * j + 1] * (pi[1] - e.cws[0][1]) +
+                   e.ci[3 * j + 2] * (pi[2] - e.cws[0][2]);
+    a[0] = 1.0f - a[1] - a[2] - a[3];
+}
+
+__device__ inline void pc_of(const EpnpState &e, const double *a, double *pc)
+{
+    for (int j = 0; j < 3; j++) {
+        const double v = a[0] * e.ccs[0][j] + a[1] * e.ccs[1][j] + a[2] * e.ccs[2][j] +
+                         a[3] * e.ccs[3][j];
+        pc[j] = e.flip ? -v : v;
+    }
+}
+
+__device__ void choose_control_points(const Points &P, EpnpState &e, EpnpLds &S)
+{
+    const int n = P.n;
+    e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
+    for (int i = 0; i < n; i++) {
+        double pw[3];
+        P.world(i, pw);
+        for (int j = 0; j < 3; j++)
+            e.cws[0][j] += pw[j];
+    }
+    for (int j = 0; j < 3; j++)
+        e.cws[0][j] /= n;
+    double m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
+    for (int i = 0; i < n; i++) {
+        double pw[3];
+        P.world(i, pw);
+        const double d0 = pw[0] - e.cws[0][0], d1 = pw[1] - e.cws[0][1], d2 = pw[2] - e.cws[0][2];
+        m00 += d0 * d0; m01 += d0 * d1; m02 += d0 * d2;
+        m11 += d1 * d1; m12 += d1 * d2; m22 += d2 * d2;
+    }
+    // symmetric, so the transposed copy the SVD works on equals the matrix
+    S.sa[0] = m00; S.sa[1] = m01; S.sa[2] = m02;
+    S.sa[3] = m01; S.sa[4] = m11; S.sa[5] = m12;
+    S.sa[6] = m02; S.sa[7] = m12; S.sa[8] = m22;
+    svd_small_square(S, 3);
+    for (int i = 1; i < 4; i++) {
+        const double k = sqrt(S.sw[i - 1] / n);
+        for (int j = 0; j < 3; j++)
+            e.cws[i][j] = e.cws[0][j] + k * S.sa[3 * (i - 1) + j];
+    }
+}
+
+// cv::invert(CC, DECOMP_SVD) of the 3 x 3 control-point basis.
+__device__ void compute_basis_inverse(EpnpState &e, EpnpLds &S)
+{
+    double cc[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 1; j < 4; j++)
+            cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            S.sa[i * 3 + j] = cc[j * 3 + i];
+    svd_small_square(S, 3);
+    const double threshold = (S.sw[0] + S.sw[1] + S.sw[2]) * (DBL_EPSILON * 2);
+    for (int i = 0; i < 9; i++)
+        e.ci[i] = 0;
+    for (int i = 0; i < 3; i++) {
+        double wi = S.sw[i];
+        if (fabs(wi) <= threshold)
+            continue;
+        wi = 1 / wi;
+        double buffer[3];
+        for (int j = 0; j < 3; j++)
+            buffer[j] = S.sa[i * 3 + j] * wi;
+        for (int r = 0; r < 3; r++) {
+            const double s = S.sv[i * 3 + r];
+            for (int j = 0; j < 3; j++)
+                e.ci[r * 3 + j] = e.ci[r * 3 + j] + s * buffer[j];
+        }
+    }
+}
+
+// MtM = M^T M accumulated point by point (rows 2i and 2i+1 of M in that order);
+// the structurally zero products are skipped, which leaves every sum unchanged.
+__device__ void accumulate_mtm(const Points &P, const EpnpState &e, EpnpLds &S)
+{
+    for (int i = 0; i < 144; i++)
+        S.ut[i] = 0;
+    for (int i = 0; i < P.n; i++) {
+        double pw[3], as[4], u, v, m1[12], m2[12];
+        P.world(i, pw);
+        P.pixel(i, u, v);
+        alphas_of(e, pw, as);
+        for (int k = 0; k < 4; k++) {
+            m1[3 * k] = as[k] * P.fu;
+            m1[3 * k + 1] = 0.0;
+            m1[3 * k + 2] = as[k] * (P.uc - u);
+            m2[3 * k] = 0.0;
+            m2[3 * k + 1] = as[k] * P.fv;
+            m2[3 * k + 2] = as[k] * (P.vc - v);
+        }
+        for (int a = 0; a < 12; a++)
+            for (int b = a; b < 12; b++) {
+                double s = S.ut[a * 12 + b];
+                if (a % 3 != 1 && b % 3 != 1)
+                    s += m1[a] * m1[b];
+                if (a % 3 != 0 && b % 3 != 0)
+                    s += m2[a] * m2[b];
+                S.ut[a * 12 + b] = s;
+            }
+    }
+    for (int a = 0; a < 12; a++)
+        for (int b = a + 1; b < 12; b++)
+            S.ut[b * 12 + a] = S.ut[a * 12 + b];
+}
+
+__device__ void compute_L_6x10(const double *ut, double *l)
+{
+    const double *v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
+    double dv[4][6][3];
+    for (int i = 0; i < 4; i++) {
+        int a = 0, b = 1;
+        for (int j = 0; j < 6; j++) {
+            dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
+            dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
+            dv[i][j][2] = v[i][3 * a + 2] - v[i][3 * b + 2];
+            b++;
+            if (b > 3) {
+                a++;
+                b = a + 1;
+            }
+        }
+    }
+    for (int i = 0; i < 6; i++) {
+        double *row = l + 10 * i;
+        row[0] = dot3(dv[0][i], dv[0][i]);
+        row[1] = 2.0f * dot3(dv[0][i], dv[1][i]);
+        row[2] = dot3(dv[1][i], dv[1][i]);
+        row[3] = 2.0f * dot3(dv[0][i], dv[2][i]);
+        row[4] = 2.0f * dot3(dv[1][i], dv[2][i]);
+        row[5] = dot3(dv[2][i], dv[2][i]);
+        row[6] = 2.0f * dot3(dv[0][i], dv[3][i]);
+        row[7] = 2.0f * dot3(dv[1][i], dv[3][i]);
+        row[8] = 2.0f * dot3(dv[2][i], dv[3][i]);
+        row[9] = dot3(dv[3][i], dv[3][i]);
+    }
+}
+
+// betas10 = [B11 B12 B22 B13 B23 B33 B14 B24 B34 B44]
+__device__ void find_betas_approx(int which, EpnpLds &S, const double *rho, double *betas)
+{
+    const double *l = S.l;
+    double sub[30], b5[5];
+    if (which == 1) { // [B11 B12 B13 B14]
+        for (int i = 0; i < 6; i++) {
+            sub[4 * i] = l[10 * i];
+            sub[4 * i + 1] = l[10 * i + 1];
+            sub[4 * i + 2] = l[10 * i + 3];
+            sub[4 * i + 3] = l[10 * i + 6];
+        }
+        solve_svd(S, sub, 6, 4, rho, b5);
+        if (b5[0] < 0) {
+            betas[0] = sqrt(-b5[0]);
+            betas[1] = -b5[1] / betas[0];
+            betas[2] = -b5[2] / betas[0];
+            betas[3] = -b5[3] / betas[0];
+        } else {
+            betas[0] = sqrt(b5[0]);
+            betas[1] = b5[1] / betas[0];
+            betas[2] = b5[2] / betas[0];
+            betas[3] = b5[3] / betas[0];
+        }
+        return;
+    }
+    const int nc = which == 2 ? 3 : 5; // [B11 B12 B22] or [B11 B12 B22 B13 B23]
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < nc; j++)
+            sub[nc * i + j] = l[10 * i + j];
+    solve_svd(S, sub, 6, nc, rho, b5);
+    if (b5[0] < 0) {
+        betas[0] = sqrt(-b5[0]);
+        betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
+    } else {
+        betas[0] = sqrt(b5[0]);
+        betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0;
+    }
+    if (b5[1] < 0)
+        betas[0] = -betas[0];
+    betas[2] = which == 2 ? 0.0 : b5[3] / betas[0];
+    betas[3] = 0.0;
+}
+
+// epnp::qr_solve on the 6 x 4 system in S.ga (Householder, in place).  The
+// column-maximum scan covers rows k..nr-2 only, as in the source it follows.
+__device__ void qr_solve(double *pA, double *pb, double *pX)
+{
+    const int nr = 6, nc = 4;
+    double A1[4], A2[4];
+    double *ppAkk = pA;
+    for (int k = 0; k < nc; k++) {
+        double *ppAik1 = ppAkk, eta = fabs(*ppAik1);
+        for (int i = k + 1; i < nr; i++) {
+            const double elt = fabs(*ppAik1);
+            if (eta < elt)
+                eta = elt;
+            ppAik1 += nc;
+        }
+        if (eta == 0)
+            return;
+        double *ppAik2 = ppAkk, sum2 = 0.0;
+        const double inv_eta = 1. / eta;
+        for (int i = k; i < nr; i++) {
+            *ppAik2 *= inv_eta;
+            sum2 += *ppAik2 * *ppAik2;
+            ppAik2 += nc;
+        }
+        double sigma = sqrt(sum2);
+        if (*ppAkk < 0)
+            sigma = -sigma;
+        *ppAkk += sigma;
+        A1[k] = sigma * *ppAkk;
+        A2[k] = -eta * sigma;
+        for (int j = k + 1; j < nc; j++) {
+            double *ppAik = ppAkk, sum = 0;
+            for (int i = k; i < nr; i++) {
+                sum += *ppAik * ppAik[j - k];
+                ppAik += nc;
+            }
+            const double tau = sum / A1[k];
+            ppAik = ppAkk;
+            for (int i = k; i < nr; i++) {
+                ppAik[j - k] -= tau * *ppAik;
+                ppAik += nc;
+            }
+        }
+        ppAkk += nc + 1;
+    }
+    double *ppAjj = pA;
+    for (int j = 0; j < nc; j++) {
+        double *ppAij = ppAjj, tau = 0;
+        for (int i = j; i < nr; i++) {
+            tau += *ppAij * pb[i];
+            ppAij += nc;
+        }
+        tau /= A1[j];
+        ppAij = ppAjj;
+        for (int i = j; i < nr; i++) {
+            pb[i] -= tau * *ppAij;
+            ppAij += nc;
+        }
+        ppAjj += nc + 1;
+    }
+    pX[nc - 1] = pb[nc - 1] / A2[nc - 1];
+    for (int i = nc - 2; i >= 0; i--) {
+        double *ppAij = pA + i * nc + (i + 1), sum = 0;
+        for (int j = i + 1; j < nc; j++) {
+            sum += *ppAij * pX[j];
+            ppAij++;
+        }
+        pX[i] = (pb[i] - sum) / A2[i];
+    }
+}
+
+__device__ void gauss_newton(EpnpLds &S, const double *rho, double *bt)
+{
+    double b[6], x[4] = {0, 0, 0, 0};
+    for (int it = 0; it < 5; it++) {
+        for (int i = 0; i < 6; i++) {
+            const double *rowL = S.l + i * 10;
+            double *rowA = S.ga + i * 4;
+            rowA[0] = 2 * rowL[0] * bt[0] + rowL[1] * bt[1] + rowL[3] * bt[2] + rowL[6] * bt[3];
+            rowA[1] = rowL[1] * bt[0] + 2 * rowL[2] * bt[1] + rowL[4] * bt[2] + rowL[7] * bt[3];
+            rowA[2] = rowL[3] * bt[0] + rowL[4] * bt[1] + 2 * rowL[5] * bt[2] + rowL[8] * bt[3];
+            rowA[3] = rowL[6] * bt[0] + rowL[7] * bt[1] + rowL[8] * bt[2] + 2 * rowL[9] * bt[3];
+            b[i] = rho[i] -
+                   (rowL[0] * bt[0] * bt[0] + rowL[1] * bt[0] * bt[1] + rowL[2] * bt[1] * bt[1] +
+                    rowL[3] * bt[0] * bt[2] + rowL[4] * bt[1] * bt[2] + rowL[5] * bt[2] * bt[2] +
+                    rowL[6] * bt[0] * bt[3] + rowL[7] * bt[1] * bt[3] + rowL[8] * bt[2] * bt[3] +
+                    rowL[9] * bt[3] * bt[3]);
+        }
+        qr_solve(S.ga, b, x);
+        for (int i = 0; i < 4; i++)
+            bt[i] += x[i];
+    }
+}
+
+// compute_ccs, compute_pcs, solve_for_sign, estimate_R_and_t, reprojection_error.
+__device__ double compute_R_and_t(const Points &P, EpnpState &e, EpnpLds &S, const double *betas,
+                                  double R[3][3], double t[3])
+{
+    const int n = P.n;
+    for (int i = 0; i < 4; i++)
+        e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0f;
+    for (int i = 0; i < 4; i++) {
+        const double *v = S.ut + 12 * (11 - i);
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++)
+                e.ccs[j][k] += betas[i] * v[3 * j + k];
+    }
+    // solve_for_sign: the first point's depth decides the sign of everything
+    {
+        double pw[3], a[4], pc[3];
+        P.world(0, pw);
+        alphas_of(e, pw, a);
+        e.flip = false;
+        pc_of(e, a, pc);
+        e.flip = pc[2] < 0.0;
+    }
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        double pw[3], a[4], pc[3];
+        P.world(i, pw);
+        alphas_of(e, pw, a);
+        pc_of(e, a, pc);
+        for (int j = 0; j < 3; j++) {
+            pc0[j] += pc[j];
+            pw0[j] += pw[j];
+        }
+    }
+    for (int j = 0; j < 3; j++) {
+        pc0[j] /= n;
+        pw0[j] /= n;
+    }
+    double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        double pw[3], a[4], pc[3];
+        P.world(i, pw);
+        alphas_of(e, pw, a);
+        pc_of(e, a, pc);
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+            abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+            abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+        }
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            S.sa[i * 3 + j] = abt[j * 3 + i];
+    svd_small_square(S, 3);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R[i][j] = S.sa[0 * 3 + i] * S.sv[0 * 3 + j] + S.sa[1 * 3 + i] * S.sv[1 * 3 + j] +
+                      S.sa[2 * 3 + i] * S.sv[2 * 3 + j];
+    const double det = R[0][0] * R[1][1] * R[2][2] + R[0][1] * R[1][2] * R[2][0] +
+                       R[0][2] * R[1][0] * R[2][1] - R[0][2] * R[1][1] * R[2][0] -
+                       R[0][1] * R[1][0] * R[2][2] - R[0][0] * R[1][2] * R[2][1];
+    if (det < 0) {
+        R[2][0] = -R[2][0];
+        R[2][1] = -R[2][1];
+        R[2][2] = -R[2][2];
+    }
+    t[0] = pc0[0] - dot3(R[0], pw0);
+    t[1] = pc0[1] - dot3(R[1], pw0);
+    t[2] = pc0[2] - dot3(R[2], pw0);
+    double sum2 = 0.0;
+    for (int i = 0; i < n; i++) {
+        double pw[3], u, v;
+        P.world(i, pw);
+        P.pixel(i, u, v);
+        const double Xc = dot3(R[0], pw) + t[0];
+        const double Yc = dot3(R[1], pw) + t[1];
+        const double inv_Zc = 1.0 / (dot3(R[2], pw) + t[2]);
+        const double ue = P.uc + P.fu * Xc * inv_Zc;
+        const double ve = P.vc + P.fv * Yc * inv_Zc;
+        sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+    }
+    return sum2 / n;
+}
+
+// epnp::compute_pose on the correspondences P.
+__device__ void epnp_pose(const Points &P, EpnpLds &S, double R[3][3], double t[3])
+{
+    EpnpState e;
+    choose_control_points(P, e, S);
+    compute_basis_inverse(e, S);
+    accumulate_mtm(P, e, S);
+    jacobi_svd(S.ut, 12, S.w, S.vt, 12, 12, 12); // MtM is symmetric: its transpose is itself
+    compute_L_6x10(S.ut, S.l);
+    double rho[6];
+    rho[0] = dist2(e.cws[0], e.cws[1]);
+    rho[1] = dist2(e.cws[0], e.cws[2]);
+    rho[2] = dist2(e.cws[0], e.cws[3]);
+    rho[3] = dist2(e.cws[1], e.cws[2]);
+    rho[4] = dist2(e.cws[1], e.cws[3]);
+    rho[5] = dist2(e.cws[2], e.cws[3]);
+    double best_err = 0;
+    for (int c = 1; c <= 3; c++) {
+        double betas[4], Rc[3][3], tc[3];
+        find_betas_approx(c, S, rho, betas);
+        gauss_newton(S, rho, betas);
+        const double err = compute_R_and_t(P, e, S, betas, Rc, tc);
+        // N = 1; if (err2 < err1) N = 2; if (err3 < err[N]) N = 3
+        if (c == 1 || err < best_err) {
+            best_err = err;
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++)
+                    R[i][j] = Rc[i][j];
+                t[i] = tc[i];
+            }
+        }
+    }
+}
+
+// cv::Rodrigues matrix -> vector (R re-orthonormalised by SVD first).
+__device__ void rodrigues_mat_to_vec(EpnpLds &S, const double Rin[3][3], double r[3])
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            if (!(fabs(Rin[i][j]) < 100.)) {
+                r[0] = r[1] = r[2] = 0;
+                return;
+            }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            S.sa[i * 3 + j] = Rin[j][i];
+    svd_small_square(S, 3);
+    double R[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R[i * 3 + j] = S.sa[0 * 3 + i] * S.sv[0 * 3 + j] + S.sa[1 * 3 + i] * S.sv[1 * 3 + j] +
+                           S.sa[2 * 3 + i] * S.sv[2 * 3 + j];
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0)
+            rx = ry = rz = 0;
+        else {
+            double q;
+            q = (R[0] + 1) * 0.5;
+            rx = sqrt(q > 0. ? q : 0.);
+            q = (R[4] + 1) * 0.5;
+            ry = sqrt(q > 0. ? q : 0.) * (R[1] < 0 ? -1. : 1.);
+            q = (R[8] + 1) * 0.5;
+            rz = sqrt(q > 0. ? q : 0.) * (R[2] < 0 ? -1. : 1.);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0))
+                rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta;
+            ry *= theta;
+            rz *= theta;
+        }
+    } else {
+        double vth = 1 / (2 * s);
+        vth *= theta;
+        rx *= vth;
+        ry *= vth;
+        rz *= vth;
+    }
+    r[0] = rx;
+    r[1] = ry;
+    r[2] = rz;
+}
+
+// cv::Rodrigues vector -> matrix.
+__device__ void rodrigues_vec_to_mat(const double r[3], double R[9])
+{
+    const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (theta < DBL_EPSILON) {
+        for (int i = 0; i < 9; i++)
+            R[i] = (i % 4 == 0) ? 1. : 0.;
+        return;
+    }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+    const double x = r[0] * itheta, y = r[1] * itheta, z = r[2] * itheta;
+    const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+    const double r_x[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    for (int i = 0; i < 9; i++)
+        R[i] = c * ((i % 4 == 0) ? 1. : 0.) + c1 * rrt[i] + s * r_x[i];
+}
+
+// projectPoints (zero distortion) + float squared error + threshold test of
+// PnPRansacCallback::computeError / findInliers for point i.
+__device__ inline bool is_inlier(const float *obj, const float *img, int64_t i, const double *R,
+                                 const double *t, double fx, double fy, double cx, double cy,
+                                 float thr2)
+{
+    const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+    double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    z = z ? 1. / z : 1;
+    x *= z;
+    y *= z;
+    const float px = (float)(x * fx + cx), py = (float)(y * fy + cy);
+    const float dx = img[2 * i] - px, dy = img[2 * i + 1] - py;
+    const float err = dx * dx + dy * dy;
+    return err <= thr2;
+}
+
+__device__ inline Points make_points(const float *obj, const float *img, const int32_t *idx, int n,
+                                     CameraK K)
+{
+    Points P;
+    P.obj = obj;
+    P.img = img;
+    P.idx = idx;
+    P.n = n;
+    P.fu = K.fx;
+    P.fv = K.fy;
+    P.uc = K.cx;
+    P.vc = K.cy;
+    P.ifx = 1. / K.fx;
+    P.ify = 1. / K.fy;
+    return P;
+}
+
+} // namespace
+
+// One workgroup (one wave) per hypothesis h: EPnP on rows subsets[5h .. 5h+5),
+// model (rvec, tvec) -> models[6h..], inlier count over all n rows -> counts[h].
+__global__ __launch_bounds__(64) void ransac_hypotheses_kernel(
+    const float *__restrict__ obj, const float *__restrict__ img, int n, CameraK K,
+    const int32_t *__restrict__ subsets, int n_hyp, float thr2, double *__restrict__ models,
+    int32_t *__restrict__ counts)
+{
+    __shared__ EpnpLds S;
+    const int h = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        const Points P = make_points(obj, img, subsets + (int64_t)h * 5, 5, K);
+        double R[3][3], t[3], r[3];
+        epnp_pose(P, S, R, t);
+        rodrigues_mat_to_vec(S, R, r);
+        S.out[0] = r[0]; S.out[1] = r[1]; S.out[2] = r[2];
+        S.out[3] = t[0]; S.out[4] = t[1]; S.out[5] = t[2];
+        rodrigues_vec_to_mat(r, S.out + 6);
+        for (int i = 0; i < 6; i++)
+            models[(int64_t)h * 6 + i] = S.out[i];
+    }
+    __syncthreads();
+    double Rm[9], tv[3];
+    for (int i = 0; i < 9; i++)
+        Rm[i] = S.out[6 + i];
+    for (int i = 0; i < 3; i++)
+        tv[i] = S.out[3 + i];
+    int good = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool f = i < n && is_inlier(obj, img, i, Rm, tv, K.fx, K.fy, K.cx, K.cy, thr2);
+        good += __builtin_popcountll(__ballot(f));
+    }
+    if (lane == 0)
+        counts[h] = good;
+}
+
+// Inlier mask of one model (rvec|tvec in model[6]) over all n rows.
+__global__ __launch_bounds__(256) void inlier_mask_kernel(const float *__restrict__ obj,
+                                                          const float *__restrict__ img, int n,
+                                                          CameraK K,
+                                                          const double *__restrict__ model,
+                                                          float thr2, uint8_t *__restrict__ mask)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    double r[3] = {model[0], model[1], model[2]}, t[3] = {model[3], model[4], model[5]}, R[9];
+    rodrigues_vec_to_mat(r, R);
+    mask[i] = is_inlier(obj, img, i, R, t, K.fx, K.fy, K.cx, K.cy, thr2) ? 1 : 0;
+}
+
+// solvePnP(SOLVEPNP_EPNP) on rows idx[0..n) (idx may be null): model[6] = rvec|tvec.
+__global__ __launch_bounds__(64) void epnp_solve_kernel(const float *__restrict__ obj,
+                                                        const float *__restrict__ img,
+                                                        const int32_t *__restrict__ idx, int n,
+                                                        CameraK K, double *__restrict__ model)
+{
+    __shared__ EpnpLds S;
+    if (threadIdx.x == 0) {
+        const Points P = make_points(obj, img, idx, n, K);
+        double R[3][3], t[3], r[3];
+        epnp_pose(P, S, R, t);
+        rodrigues_mat_to_vec(S, R, r);
+        model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
+        model[3] = t[0]; model[4] = t[1]; model[5] = t[2];
+    }
+}
+
+hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int n, CameraK K,
+                                    const int32_t *d_subsets, int n_hyp, float thr2,
+                                    double *d_models, int32_t *d_counts, hipStream_t stream)
+{
+    if (n_hyp <= 0)
+        return hipSuccess;
+    ransac_hypotheses_kernel<<<n_hyp, 64, 0, stream>>>(d_obj, d_img, n, K, d_subsets, n_hyp, thr2,
+                                                       d_models, d_counts);
+    return hipGetLastError();
+}
+
+hipError_t inlier_mask_launch(const float *d_obj, const float *d_img, int n, CameraK K,
+                              const double *d_model, float thr2, uint8_t *d_mask,
+                              hipStream_t stream)
+{
+    if (n <= 0)
+        return hipSuccess;
+    inlier_mask_kernel<<<(n + 255) / 256, 256, 0, stream>>>(d_obj, d_img, n, K, d_model, thr2,
+                                                            d_mask);
+    return hipGetLastError();
+}
+
+hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,
+                             CameraK K, double *d_model, hipStream_t stream)
+{
+    epnp_solve_kernel<<<1, 64, 0, stream>>>(d_obj, d_img, d_idx, n, K, d_model);
+    return hipGetLastError();
+}
+
+} // namespace posehip

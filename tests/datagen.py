@@ -45,3 +45,45 @@ def numpy_knn(q, t, k):
     idx[:, :kk] = order
     dist[:, :kk] = np.take_along_axis(d, order, axis=1)
     return idx, dist
+
+
+# ---- 2D-3D correspondences of the cereal-box scene --------------------------------
+# Box half extents (src/cereal_box.cpp:98-100), camera of glm::perspective(45 deg,
+# 800/600) (src/cereal_box.cpp:219-222): fy = 300 / tan(22.5 deg), square pixels.
+BOX_HALF = np.array([1.0, 1.2934, 0.41149])
+FOCAL = 300.0 / np.tan(np.radians(22.5))
+CAMERA_K = np.array([[FOCAL, 0.0, 400.0], [0.0, FOCAL, 300.0], [0.0, 0.0, 1.0]])
+
+
+def axis_angle_matrix(axis, angle):
+    axis = np.asarray(axis, np.float64)
+    axis = axis / np.linalg.norm(axis)
+    x, y, z = axis
+    c, s = np.cos(angle), np.sin(angle)
+    Kx = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
+    return c * np.eye(3) + (1 - c) * np.outer(axis, axis) + s * Kx
+
+
+def pnp_scene(n=2000, outlier_frac=0.3, noise_px=1.0, seed=3, angle_deg=50.0 * 0.7,
+              t=(0.0, 0.0, 6.0), on_faces=False):
+    """(obj[n,3] f32, img[n,2] f32, R_gt, t_gt, is_inlier[n]).
+
+    Points uniform in the box volume (or on its faces), pose = rotation about
+    (0.3, 1, 0) (src/cereal_box.cpp:263) and the camera 6 units away; inliers get
+    N(0, noise_px) pixel noise, outliers are uniform in the 800x600 frame.
+    """
+    rng = np.random.default_rng(seed)
+    obj = (rng.random((n, 3)) * 2 - 1) * BOX_HALF
+    if on_faces:
+        face = rng.integers(0, 3, size=n)
+        sign = rng.integers(0, 2, size=n) * 2 - 1
+        obj[np.arange(n), face] = sign * BOX_HALF[face]
+    R = axis_angle_matrix((0.3, 1.0, 0.0), np.radians(angle_deg))
+    tv = np.asarray(t, np.float64)
+    cam = obj @ R.T + tv
+    px = cam[:, :2] / cam[:, 2:3] * FOCAL + np.array([400.0, 300.0])
+    px += rng.normal(0.0, noise_px, size=px.shape)
+    is_inlier = rng.random(n) >= outlier_frac
+    out_px = rng.random((n, 2)) * np.array([800.0, 600.0])
+    img = np.where(is_inlier[:, None], px, out_px)
+    return obj.astype(np.float32), img.astype(np.float32), R, tv, is_inlier

@@ -53,6 +53,27 @@ def load():
     lib.orc_min_dist_filter.argtypes = [_dmp, C.c_int, _dmp]
     lib.orc_sort_by_distance.restype = None
     lib.orc_sort_by_distance.argtypes = [_dmp, C.c_int]
+    _f32p, _f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    lib.orc_ransac_subsets.restype = None
+    lib.orc_ransac_subsets.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, _i32p]
+    lib.orc_ransac_update_num_iters.restype = C.c_int
+    lib.orc_ransac_update_num_iters.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+    lib.orc_rodrigues_mat_to_vec.restype = None
+    lib.orc_rodrigues_mat_to_vec.argtypes = [_f64p, _f64p]
+    lib.orc_rodrigues_vec_to_mat.restype = None
+    lib.orc_rodrigues_vec_to_mat.argtypes = [_f64p, _f64p]
+    lib.orc_solvepnp_epnp.restype = C.c_int
+    lib.orc_solvepnp_epnp.argtypes = [_f32p, _f32p, C.c_int, _f64p, _f64p, _f64p]
+    lib.orc_pnp_count_inliers.restype = C.c_int
+    lib.orc_pnp_count_inliers.argtypes = [_f32p, _f32p, C.c_int, _f64p, _f64p, _f64p, C.c_double,
+                                          _u8p, _f32p]
+    lib.orc_pnp_hypotheses.restype = C.c_int
+    lib.orc_pnp_hypotheses.argtypes = [_f32p, _f32p, C.c_int, _f64p, _i32p, C.c_int, C.c_double,
+                                       _f64p, _i32p, C.c_int]
+    lib.orc_solvepnp_ransac.restype = C.c_int
+    lib.orc_solvepnp_ransac.argtypes = [_f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_float,
+                                        C.c_double, C.c_uint64, _f64p, _f64p, _i32p,
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = lib
     return lib
 
@@ -123,3 +144,93 @@ def sort_by_distance(matches):
     buf = (DMatchC * max(n, 1))(*[DMatchC(*m) for m in matches])
     load().orc_sort_by_distance(buf, n)
     return _tuples(buf, n)
+
+
+# ---- RANSAC-EPnP -------------------------------------------------------------
+CV_RNG_DEFAULT = 0xFFFFFFFFFFFFFFFF  # RNG rng((uint64)-1) in RANSACPointSetRegistrator::run
+
+
+def _f32(a, cols):
+    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1, cols)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _K(K):
+    return np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+
+
+def ransac_subsets(n_points, n_subsets, rng_state=CV_RNG_DEFAULT, model_points=5):
+    out = np.empty((n_subsets, model_points), np.int32)
+    load().orc_ransac_subsets(rng_state, n_points, model_points, n_subsets,
+                              out.ctypes.data_as(_i32p))
+    return out
+
+
+def update_num_iters(p, ep, model_points, max_iters):
+    return load().orc_ransac_update_num_iters(p, ep, model_points, max_iters)
+
+
+def rodrigues(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if x.size == 9:
+        r = np.empty(3)
+        load().orc_rodrigues_mat_to_vec(_dp(x.reshape(9)), _dp(r))
+        return r
+    R = np.empty(9)
+    load().orc_rodrigues_vec_to_mat(_dp(x.reshape(3)), _dp(R))
+    return R.reshape(3, 3)
+
+
+def solvepnp_epnp(obj, img, K):
+    obj, img, K = _f32(obj, 3), _f32(img, 2), _K(K)
+    r, t = np.empty(3), np.empty(3)
+    rc = load().orc_solvepnp_epnp(_fp(obj), _fp(img), obj.shape[0], _dp(K), _dp(r), _dp(t))
+    assert rc == 0
+    return r, t
+
+
+def count_inliers(obj, img, K, rvec, tvec, threshold=8.0):
+    obj, img, K = _f32(obj, 3), _f32(img, 2), _K(K)
+    n = obj.shape[0]
+    mask = np.empty(n, np.uint8)
+    err = np.empty(n, np.float32)
+    rvec = np.ascontiguousarray(rvec, np.float64)
+    tvec = np.ascontiguousarray(tvec, np.float64)
+    good = load().orc_pnp_count_inliers(_fp(obj), _fp(img), n, _dp(K), _dp(rvec), _dp(tvec),
+                                        threshold, mask.ctypes.data_as(_u8p), _fp(err))
+    return good, mask, err
+
+
+def pnp_hypotheses(obj, img, K, subsets, threshold=8.0, threads=1):
+    """(models[n_hyp, 6] = rvec|tvec, counts[n_hyp])."""
+    obj, img, K = _f32(obj, 3), _f32(img, 2), _K(K)
+    subsets = np.ascontiguousarray(subsets, np.int32)
+    h = subsets.shape[0]
+    models = np.empty((h, 6), np.float64)
+    counts = np.empty(h, np.int32)
+    rc = load().orc_pnp_hypotheses(_fp(obj), _fp(img), obj.shape[0], _dp(K),
+                                   subsets.ctypes.data_as(_i32p), h, threshold, _dp(models),
+                                   counts.ctypes.data_as(_i32p), threads)
+    assert rc == 0
+    return models, counts
+
+
+def solvepnp_ransac(obj, img, K, iterations=100, reproj_err=8.0, confidence=0.99,
+                    rng_state=CV_RNG_DEFAULT):
+    """(ok, rvec, tvec, inliers, iterations_run)."""
+    obj, img, K = _f32(obj, 3), _f32(img, 2), _K(K)
+    n = obj.shape[0]
+    r, t = np.zeros(3), np.zeros(3)
+    inl = np.empty(max(n, 1), np.int32)
+    n_inl, iters = C.c_int(0), C.c_int(0)
+    rc = load().orc_solvepnp_ransac(_fp(obj), _fp(img), n, _dp(K), iterations, reproj_err,
+                                    confidence, rng_state, _dp(r), _dp(t),
+                                    inl.ctypes.data_as(_i32p), C.byref(n_inl), C.byref(iters))
+    return rc == 1, r, t, inl[:n_inl.value].copy(), iters.value

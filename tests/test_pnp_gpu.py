@@ -1,0 +1,146 @@
+"""GPU suite: RANSAC-EPnP on the GPU against the CPU oracle.
+
+Tolerances: poses must agree within 1e-4 relative rotation / translation error
+(the metric of the reference's src/evaluation/Evaluation.py:5-15) for identical
+RANSAC seeds; inlier counts and index lists are compared exactly.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import datagen
+import oracle_bind as orc
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4
+
+
+def rel_translation_error(t_est, t_gt):
+    return np.linalg.norm(t_gt - t_est) / np.linalg.norm(t_est)
+
+
+def rel_rotation_error(R_est, R_gt):
+    return np.linalg.norm(R_gt - R_est) / np.linalg.norm(R_est)
+
+
+def assert_same_pose(r_a, t_a, r_b, t_b, tol=POSE_TOL):
+    Ra, Rb = orc.rodrigues(np.ravel(r_a)), orc.rodrigues(np.ravel(r_b))
+    assert rel_rotation_error(Ra, Rb) <= tol
+    assert rel_translation_error(np.ravel(t_a), np.ravel(t_b)) <= tol
+
+
+def gpu_hypotheses(lib, obj, img, K, subsets, thr=8.0):
+    import torch
+    dev = torch.device("cuda", 0)
+    d_obj = torch.from_numpy(obj).to(dev)
+    d_img = torch.from_numpy(img).to(dev)
+    d_sub = torch.from_numpy(subsets).to(dev)
+    h = subsets.shape[0]
+    d_models = torch.zeros((h, 6), dtype=torch.float64, device=dev)
+    d_counts = torch.zeros(h, dtype=torch.int32, device=dev)
+    Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+    torch.cuda.synchronize()
+    lib.check(lib.load().ph_ransac_epnp_hypotheses_dev(
+        d_obj.data_ptr(), d_img.data_ptr(), obj.shape[0], Kc.ctypes.data_as(C.POINTER(C.c_double)),
+        d_sub.data_ptr(), h, thr, d_models.data_ptr(), d_counts.data_ptr(), None))
+    lib.check(lib.load().ph_stream_synchronize(None))
+    return d_models.cpu().numpy(), d_counts.cpu().numpy()
+
+
+def test_subset_stream_matches_cv_rng(posehip):
+    want = orc.ransac_subsets(2000, 300)
+    got = np.empty((300, 5), np.int32)
+    posehip.check(posehip.load().ph_ransac_subsets(orc.CV_RNG_DEFAULT, 2000, 300,
+                                                   got.ctypes.data_as(C.POINTER(C.c_int32))))
+    assert np.array_equal(got, want)
+    assert all(len(set(r)) == 5 for r in got.tolist())
+
+
+@pytest.mark.parametrize("seed,on_faces", [(3, False), (4, True)])
+def test_hypotheses_match_oracle(posehip, seed, on_faces):
+    obj, img, R, t, inl = datagen.pnp_scene(n=2000, seed=seed, on_faces=on_faces)
+    subsets = orc.ransac_subsets(2000, 512)
+    models, counts = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, subsets)
+    rmodels, rcounts = orc.pnp_hypotheses(obj, img, datagen.CAMERA_K, subsets)
+    same = counts == rcounts
+    assert same.mean() >= 0.99, f"only {same.mean():.3f} of the inlier counts agree"
+    assert counts.max() == rcounts.max() and counts.argmax() == rcounts.argmax()
+    good = np.nonzero(rcounts >= 0.5 * rcounts.max())[0]
+    assert len(good) > 10
+    for h in good:
+        assert_same_pose(models[h, :3], models[h, 3:], rmodels[h, :3], rmodels[h, 3:], 1e-6)
+
+
+def test_epnp_solve_matches_oracle(posehip):
+    import poseestimation_amd as pa
+    for n, seed in [(4, 1), (5, 2), (6, 3), (50, 4), (700, 5)]:
+        obj, img, R, t, _ = datagen.pnp_scene(n=n, outlier_frac=0.0, noise_px=0.5, seed=seed)
+        ok, rvec, tvec = pa.solvePnP(obj, img, datagen.CAMERA_K, None, flags=pa.SOLVEPNP_EPNP)
+        r0, t0 = orc.solvepnp_epnp(obj, img, datagen.CAMERA_K)
+        assert ok
+        assert_same_pose(rvec, tvec, r0, t0, 1e-9)
+
+
+@pytest.mark.parametrize("n,outliers,iters,seed", [(2000, 0.3, 4096, 3), (2000, 0.3, 100, 7),
+                                                   (500, 0.5, 1000, 8), (64, 0.1, 100, 9)])
+def test_solvepnp_ransac_matches_oracle(posehip, n, outliers, iters, seed):
+    import poseestimation_amd as pa
+    obj, img, R, t, inl = datagen.pnp_scene(n=n, outlier_frac=outliers, seed=seed)
+    ok, rvec, tvec, inliers = pa.solvePnPRansac(obj, img, datagen.CAMERA_K, None,
+                                                iterationsCount=iters, reprojectionError=8.0,
+                                                confidence=0.99, flags=pa.SOLVEPNP_EPNP)
+    ok0, r0, t0, inl0, iters0 = orc.solvepnp_ransac(obj, img, datagen.CAMERA_K, iterations=iters)
+    assert ok == ok0 and ok
+    assert np.array_equal(inliers.ravel(), inl0)
+    assert_same_pose(rvec, tvec, r0, t0)
+    # and the pose is the scene's pose (1 px noise -> well within a percent)
+    assert rel_rotation_error(orc.rodrigues(rvec.ravel()), R) < 1e-2
+    assert rel_translation_error(tvec.ravel(), t) < 1e-2
+
+
+def test_iterations_run_follows_the_adaptive_budget(posehip):
+    obj, img, R, t, inl = datagen.pnp_scene(n=2000, outlier_frac=0.3, seed=3)
+    K = np.ascontiguousarray(datagen.CAMERA_K).reshape(9)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    inl_out = np.empty(2000, np.int32)
+    n_inl, found, iters = C.c_int(0), C.c_int(0), C.c_int(0)
+    fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    posehip.check(posehip.load().ph_solvepnp_ransac_epnp(
+        obj.ctypes.data_as(fp), img.ctypes.data_as(fp), 2000, K.ctypes.data_as(dp), 4096, 8.0,
+        0.99, orc.CV_RNG_DEFAULT, rvec.ctypes.data_as(dp), tvec.ctypes.data_as(dp),
+        inl_out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n_inl), C.byref(found),
+        C.byref(iters)))
+    ok0, r0, t0, inl0, iters0 = orc.solvepnp_ransac(obj, img, datagen.CAMERA_K, iterations=4096)
+    assert found.value == 1 and iters.value == iters0 and n_inl.value == len(inl0)
+
+
+def test_five_points_and_all_outliers(posehip):
+    import poseestimation_amd as pa
+    obj, img, R, t, _ = datagen.pnp_scene(n=5, outlier_frac=0.0, noise_px=0.0, seed=11)
+    ok, rvec, tvec, inliers = pa.solvePnPRansac(obj, img, datagen.CAMERA_K, None)
+    assert ok and inliers.ravel().tolist() == [0, 1, 2, 3, 4]
+    r0, t0 = orc.solvepnp_epnp(obj, img, datagen.CAMERA_K)
+    assert_same_pose(rvec, tvec, r0, t0, 1e-9)
+    # pure noise: OpenCV's rule still accepts any model with >= 5 inliers at 8 px
+    obj, img, R, t, _ = datagen.pnp_scene(n=300, outlier_frac=1.0, seed=12)
+    ok, rvec, tvec, inliers = pa.solvePnPRansac(obj, img, datagen.CAMERA_K, None,
+                                                iterationsCount=50, reprojectionError=1.0)
+    ok0, r0, t0, inl0, _ = orc.solvepnp_ransac(obj, img, datagen.CAMERA_K, iterations=50,
+                                               reproj_err=1.0)
+    assert ok == ok0
+    if ok:
+        assert np.array_equal(inliers.ravel(), inl0)
+
+
+def test_invalid_arguments(posehip):
+    import poseestimation_amd as pa
+    obj, img, R, t, _ = datagen.pnp_scene(n=4, outlier_frac=0.0, seed=1)
+    with pytest.raises(posehip.PosehipError):
+        pa.solvePnPRansac(obj, img, datagen.CAMERA_K, None)          # n < 5
+    obj, img, R, t, _ = datagen.pnp_scene(n=20, outlier_frac=0.0, seed=1)
+    with pytest.raises(posehip.PosehipError):
+        pa.solvePnPRansac(obj, img, datagen.CAMERA_K, None, confidence=1.0)
+    with pytest.raises(ValueError):
+        pa.solvePnPRansac(obj, img, datagen.CAMERA_K, np.array([0.1, 0, 0, 0]))
