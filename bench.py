@@ -68,7 +68,10 @@ def main():
     d_idx = torch.empty((F, nq, 2), dtype=torch.int32, device=dev)
     d_dist = torch.empty((F, nq, 2), dtype=torch.int32, device=dev)
     d_keep = torch.empty((F, nq), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream()
+    # a stream of our own: the handle of torch's default stream is 0, which the
+    # C ABI reads as "use the library's stream"
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     sptr = C.c_void_p(stream.cuda_stream)
     qp = [d_q[f].data_ptr() for f in range(F)]
     ip = [d_idx[f].data_ptr() for f in range(F)]

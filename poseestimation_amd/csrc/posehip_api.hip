@@ -637,7 +637,8 @@ ph_status ph_ransac_epnp_hypotheses_dev(const float *d_obj, const float *d_img, 
         return fail(PH_ERR_INVALID_ARG, "need >= 5 correspondences and non-null buffers");
     const double thr = reproj_err;
     PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, camera_of(K), d_subsets, n_hyp,
-                                    (float)(thr * thr), d_models, d_counts, pick_stream(stream)));
+                                    (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
+                                    pick_stream(stream)));
     return PH_OK;
 }
 
@@ -744,7 +745,7 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
         PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, cam,
                                         (const int32_t *)g_ctx.pnp_sub.p + (size_t)base * 5, m,
                                         thr2, (double *)g_ctx.pnp_models.p,
-                                        (int32_t *)g_ctx.pnp_counts.p, st));
+                                        (int32_t *)g_ctx.pnp_counts.p, g_ctx.n_cus, st));
         PH_HIP(hipMemcpyAsync(models.data(), g_ctx.pnp_models.p, (size_t)m * 6 * sizeof(double),
                               hipMemcpyDeviceToHost, st));
         PH_HIP(hipMemcpyAsync(counts.data(), g_ctx.pnp_counts.p, (size_t)m * sizeof(int32_t),

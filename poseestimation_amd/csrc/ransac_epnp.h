@@ -13,7 +13,8 @@ struct CameraK {
 // inlier count over all n rows -> d_counts[h].  thr2 = (float)(reprojectionError^2).
 hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int n, CameraK K,
                                     const int32_t *d_subsets, int n_hyp, float thr2,
-                                    double *d_models, int32_t *d_counts, hipStream_t stream);
+                                    double *d_models, int32_t *d_counts, int n_cus,
+                                    hipStream_t stream);
 
 // One byte per row: 1 iff the row is an inlier of d_model (rvec|tvec).
 hipError_t inlier_mask_launch(const float *d_obj, const float *d_img, int n, CameraK K,

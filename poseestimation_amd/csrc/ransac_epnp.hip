@@ -8,15 +8,21 @@
 // pose from the best one), converts R to a rotation vector, and counts the
 // points whose float squared reprojection error is <= threshold^2.
 //
-// Mapping.  One hypothesis per wavefront.  The EPnP solve is a short, strictly
-// sequential fp64 computation; it runs on lane 0 with its small matrices in the
-// wave's LDS block, every operation in the same order as a plain sequential
-// statement of the algorithm (built with -ffp-contract=off) so that poses agree
-// with a CPU statement to the last bits.  Per-point quantities (barycentric
-// coordinates, camera-frame points) are recomputed where they are used instead
-// of stored, so the same routine refits on any number of inliers in O(1)
-// memory.  Scoring then uses all 64 lanes: lanes stride over the
-// correspondences and the inlier count is reduced with ballot + popcount.
+// Mapping.  The EPnP solve is a strictly sequential fp64 computation whose
+// critical path (Jacobi rotation angles: sqrt, divide, hypot per row pair) cannot
+// be spread over lanes without changing the rounding, so the solve kernel runs
+// ONE HYPOTHESIS PER LANE: every instruction of that chain serves up to 64
+// hypotheses.  Each lane keeps its small matrices (12 x 12 null-space problem,
+// 6 x 10 system, ...) in LDS, interleaved over the lanes (element e of lane l at
+// word e*HPW + l, so a wave access is conflict-free), 2472 bytes per hypothesis.
+// Every operation is in the order of a plain sequential statement of the
+// algorithm (built with -ffp-contract=off) so that poses agree with a CPU
+// statement to the last bits.  Per-point quantities (barycentric coordinates,
+// camera-frame points) are recomputed where they are used instead of stored, so
+// the same routine refits on any number of inliers in O(1) memory.
+// Scoring is a second kernel with ONE HYPOTHESIS PER WAVEFRONT: the 64 lanes
+// stride over the correspondences and the inlier count is reduced with
+// ballot + popcount.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
@@ -26,6 +32,20 @@
 namespace posehip {
 
 namespace {
+
+// Cycle stamps for the profiling tool (tools/pnp_stamps.hip defines PNP_STAMPS
+// and the array before including this file); compiled out of the library.
+#ifdef PNP_STAMPS
+#define PNP_STAMP(k)                                                                              \
+    do {                                                                                          \
+        if (blockIdx.x == 0 && threadIdx.x == 0)                                                  \
+            g_pnp_stamps[k] = clock64();                                                          \
+    } while (0)
+#else
+#define PNP_STAMP(k)                                                                              \
+    do {                                                                                          \
+    } while (0)
+#endif
 
 // ---- cv::RNG (multiply-with-carry), used by the SVD's zero-row completion ----
 struct Rng {
@@ -85,11 +105,32 @@ __device__ double hypot_cr(double x, double y)
     return hypot_kernel(ax, ay);
 }
 
+// Pointer into a lane's interleaved LDS arrays: consecutive elements of one
+// lane are ST words apart (ST = hypotheses per workgroup).
+template <int ST> struct LP {
+    double *p;
+    __device__ double &operator[](int e) const { return p[e * ST]; }
+    __device__ double &operator*() const { return *p; }
+    __device__ LP operator+(int e) const { return LP{p + e * ST}; }
+    __device__ LP &operator+=(int e)
+    {
+        p += e * ST;
+        return *this;
+    }
+    __device__ LP &operator++(int)
+    {
+        p += ST;
+        return *this;
+    }
+};
+
 // One-sided Jacobi SVD on the n rows of At (length m each); rotations
 // accumulate in Vt (n x n).  On exit the rows of At are the left singular
 // vectors, W descending.  Same sweep order, thresholds and zero-row completion
-// as OpenCV's JacobiSVDImpl_<double>.  W is an n-entry work array.
-__device__ void jacobi_svd(double *At, int astep, double *W, double *Vt, int vstep, int m, int n)
+// as OpenCV's JacobiSVDImpl_<double>.  W is an n-entry work array.  WITH_V =
+// false skips the right-vector accumulation (it never feeds back into At or W).
+template <int ST, bool WITH_V>
+__device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep, int m, int n)
 {
     const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
     const int max_iter = m > 30 ? m : 30;
@@ -101,15 +142,17 @@ __device__ void jacobi_svd(double *At, int astep, double *W, double *Vt, int vst
             sd += t * t;
         }
         W[i] = sd;
-        for (int k = 0; k < n; k++)
-            Vt[i * vstep + k] = 0;
-        Vt[i * vstep + i] = 1;
+        if (WITH_V) {
+            for (int k = 0; k < n; k++)
+                Vt[i * vstep + k] = 0;
+            Vt[i * vstep + i] = 1;
+        }
     }
     for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
         for (int i = 0; i < n - 1; i++)
             for (int j = i + 1; j < n; j++) {
-                double *Ai = At + i * astep, *Aj = At + j * astep;
+                const LP<ST> Ai = At + i * astep, Aj = At + j * astep;
                 double a = W[i], p = 0, b = W[j];
                 for (int k = 0; k < m; k++)
                     p += Ai[k] * Aj[k];
@@ -137,12 +180,14 @@ __device__ void jacobi_svd(double *At, int astep, double *W, double *Vt, int vst
                 W[i] = a;
                 W[j] = b;
                 changed = true;
-                double *Vi = Vt + i * vstep, *Vj = Vt + j * vstep;
-                for (int k = 0; k < n; k++) {
-                    const double t0 = c * Vi[k] + s * Vj[k];
-                    const double t1 = -s * Vi[k] + c * Vj[k];
-                    Vi[k] = t0;
-                    Vj[k] = t1;
+                if (WITH_V) {
+                    const LP<ST> Vi = Vt + i * vstep, Vj = Vt + j * vstep;
+                    for (int k = 0; k < n; k++) {
+                        const double t0 = c * Vi[k] + s * Vj[k];
+                        const double t1 = -s * Vi[k] + c * Vj[k];
+                        Vi[k] = t0;
+                        Vj[k] = t1;
+                    }
                 }
             }
         if (!changed)
@@ -170,11 +215,12 @@ __device__ void jacobi_svd(double *At, int astep, double *W, double *Vt, int vst
                 At[i * astep + k] = At[j * astep + k];
                 At[j * astep + k] = t;
             }
-            for (int k = 0; k < n; k++) {
-                t = Vt[i * vstep + k];
-                Vt[i * vstep + k] = Vt[j * vstep + k];
-                Vt[j * vstep + k] = t;
-            }
+            if (WITH_V)
+                for (int k = 0; k < n; k++) {
+                    t = Vt[i * vstep + k];
+                    Vt[i * vstep + k] = Vt[j * vstep + k];
+                    Vt[j * vstep + k] = t;
+                }
         }
     }
     Rng rng{0x12345678};
@@ -212,30 +258,38 @@ __device__ void jacobi_svd(double *At, int astep, double *W, double *Vt, int vst
     }
 }
 
-// Per-wave LDS block.
-struct EpnpLds {
-    double ut[144];   // 12 x 12: MtM, then its left singular vectors (rows)
-    double vt[144];
-    double w[12];
-    double sa[36];    // small SVDs: At (up to 5 x 6)
-    double sv[25];
-    double sw[8];
-    double l[60];     // L_6x10
-    double ga[24];    // Gauss-Newton A (6 x 4)
-    double out[16];   // rvec(3) tvec(3) R'(9) handed to the scoring lanes
+// A lane's LDS arrays (offsets in doubles; LDS_DOUBLES per hypothesis).
+constexpr int OFF_UT = 0;    // 12 x 12: MtM, then its left singular vectors (rows)
+constexpr int OFF_W = 144;   // 12
+constexpr int OFF_SA = 156;  // small SVDs: At (up to 5 x 6)
+constexpr int OFF_SV = 192;  // small SVDs: Vt (up to 5 x 5)
+constexpr int OFF_SW = 217;  // small SVDs: W
+constexpr int OFF_L = 225;   // L_6x10
+constexpr int OFF_GA = 285;  // Gauss-Newton A (6 x 4)
+constexpr int LDS_DOUBLES = 309;
+
+template <int ST> struct EpnpLds {
+    LP<ST> ut, w, sa, sv, sw, l, ga;
+    __device__ explicit EpnpLds(double *lane_base)
+        : ut{lane_base + OFF_UT * ST}, w{lane_base + OFF_W * ST}, sa{lane_base + OFF_SA * ST},
+          sv{lane_base + OFF_SV * ST}, sw{lane_base + OFF_SW * ST}, l{lane_base + OFF_L * ST},
+          ga{lane_base + OFF_GA * ST}
+    {
+    }
 };
 
 // SVD of a square matrix given TRANSPOSED in S.sa (n x n, n <= 3 here): after
 // the call S.sa holds Ut (rows = left singular vectors), S.sv holds Vt.
-__device__ void svd_small_square(EpnpLds &S, int n) { jacobi_svd(S.sa, n, S.sw, S.sv, n, n, n); }
-
-// cv::solve(A, b, x, DECOMP_SVD), A m x n row-major in registers/LDS via getter.
-__device__ void solve_svd(EpnpLds &S, const double *A, int m, int n, const double *b, double *x)
+template <int ST> __device__ void svd_small_square(const EpnpLds<ST> &S, int n)
 {
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < m; j++)
-            S.sa[i * m + j] = A[j * n + i];
-    jacobi_svd(S.sa, m, S.sw, S.sv, n, m, n);
+    jacobi_svd<ST, true>(S.sa, n, S.sw, S.sv, n, n, n);
+}
+
+// cv::solve(A, b, x, DECOMP_SVD) with A (m x n) already TRANSPOSED in S.sa (n x m).
+template <int ST>
+__device__ void solve_svd(const EpnpLds<ST> &S, int m, int n, const double *b, double *x)
+{
+    jacobi_svd<ST, true>(S.sa, m, S.sw, S.sv, n, m, n);
     double threshold = 0;
     for (int i = 0; i < n; i++) {
         x[i] = 0;
@@ -316,7 +370,8 @@ __device__ inline void pc_of(const EpnpState &e, const double *a, double *pc)
     }
 }
 
-__device__ void choose_control_points(const Points &P, EpnpState &e, EpnpLds &S)
+template <int ST>
+__device__ void choose_control_points(const Points &P, EpnpState &e, const EpnpLds<ST> &S)
 {
     const int n = P.n;
     e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
@@ -349,7 +404,7 @@ __device__ void choose_control_points(const Points &P, EpnpState &e, EpnpLds &S)
 }
 
 // cv::invert(CC, DECOMP_SVD) of the 3 x 3 control-point basis.
-__device__ void compute_basis_inverse(EpnpState &e, EpnpLds &S)
+template <int ST> __device__ void compute_basis_inverse(EpnpState &e, const EpnpLds<ST> &S)
 {
     double cc[9];
     for (int i = 0; i < 3; i++)
@@ -380,7 +435,8 @@ __device__ void compute_basis_inverse(EpnpState &e, EpnpLds &S)
 
 // MtM = M^T M accumulated point by point (rows 2i and 2i+1 of M in that order);
 // the structurally zero products are skipped, which leaves every sum unchanged.
-__device__ void accumulate_mtm(const Points &P, const EpnpState &e, EpnpLds &S)
+template <int ST>
+__device__ void accumulate_mtm(const Points &P, const EpnpState &e, const EpnpLds<ST> &S)
 {
     for (int i = 0; i < 144; i++)
         S.ut[i] = 0;
@@ -412,9 +468,9 @@ __device__ void accumulate_mtm(const Points &P, const EpnpState &e, EpnpLds &S)
             S.ut[b * 12 + a] = S.ut[a * 12 + b];
 }
 
-__device__ void compute_L_6x10(const double *ut, double *l)
+template <int ST> __device__ void compute_L_6x10(LP<ST> ut, LP<ST> l)
 {
-    const double *v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
+    const LP<ST> v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
     double dv[4][6][3];
     for (int i = 0; i < 4; i++) {
         int a = 0, b = 1;
@@ -430,7 +486,7 @@ __device__ void compute_L_6x10(const double *ut, double *l)
         }
     }
     for (int i = 0; i < 6; i++) {
-        double *row = l + 10 * i;
+        const LP<ST> row = l + 10 * i;
         row[0] = dot3(dv[0][i], dv[0][i]);
         row[1] = 2.0f * dot3(dv[0][i], dv[1][i]);
         row[2] = dot3(dv[1][i], dv[1][i]);
@@ -445,18 +501,19 @@ __device__ void compute_L_6x10(const double *ut, double *l)
 }
 
 // betas10 = [B11 B12 B22 B13 B23 B33 B14 B24 B34 B44]
-__device__ void find_betas_approx(int which, EpnpLds &S, const double *rho, double *betas)
+template <int ST>
+__device__ void find_betas_approx(int which, const EpnpLds<ST> &S, const double *rho, double *betas)
 {
-    const double *l = S.l;
-    double sub[30], b5[5];
-    if (which == 1) { // [B11 B12 B13 B14]
+    const LP<ST> l = S.l;
+    double b5[5];
+    if (which == 1) { // [B11 B12 B13 B14]; S.sa = transpose of the 6 x 4 system
         for (int i = 0; i < 6; i++) {
-            sub[4 * i] = l[10 * i];
-            sub[4 * i + 1] = l[10 * i + 1];
-            sub[4 * i + 2] = l[10 * i + 3];
-            sub[4 * i + 3] = l[10 * i + 6];
+            S.sa[0 * 6 + i] = l[10 * i];
+            S.sa[1 * 6 + i] = l[10 * i + 1];
+            S.sa[2 * 6 + i] = l[10 * i + 3];
+            S.sa[3 * 6 + i] = l[10 * i + 6];
         }
-        solve_svd(S, sub, 6, 4, rho, b5);
+        solve_svd(S, 6, 4, rho, b5);
         if (b5[0] < 0) {
             betas[0] = sqrt(-b5[0]);
             betas[1] = -b5[1] / betas[0];
@@ -473,8 +530,8 @@ __device__ void find_betas_approx(int which, EpnpLds &S, const double *rho, doub
     const int nc = which == 2 ? 3 : 5; // [B11 B12 B22] or [B11 B12 B22 B13 B23]
     for (int i = 0; i < 6; i++)
         for (int j = 0; j < nc; j++)
-            sub[nc * i + j] = l[10 * i + j];
-    solve_svd(S, sub, 6, nc, rho, b5);
+            S.sa[j * 6 + i] = l[10 * i + j];
+    solve_svd(S, 6, nc, rho, b5);
     if (b5[0] < 0) {
         betas[0] = sqrt(-b5[0]);
         betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
@@ -490,13 +547,14 @@ __device__ void find_betas_approx(int which, EpnpLds &S, const double *rho, doub
 
 // epnp::qr_solve on the 6 x 4 system in S.ga (Householder, in place).  The
 // column-maximum scan covers rows k..nr-2 only, as in the source it follows.
-__device__ void qr_solve(double *pA, double *pb, double *pX)
+template <int ST> __device__ void qr_solve(LP<ST> pA, double *pb, double *pX)
 {
     const int nr = 6, nc = 4;
     double A1[4], A2[4];
-    double *ppAkk = pA;
+    LP<ST> ppAkk = pA;
     for (int k = 0; k < nc; k++) {
-        double *ppAik1 = ppAkk, eta = fabs(*ppAik1);
+        LP<ST> ppAik1 = ppAkk;
+        double eta = fabs(*ppAik1);
         for (int i = k + 1; i < nr; i++) {
             const double elt = fabs(*ppAik1);
             if (eta < elt)
@@ -505,7 +563,8 @@ __device__ void qr_solve(double *pA, double *pb, double *pX)
         }
         if (eta == 0)
             return;
-        double *ppAik2 = ppAkk, sum2 = 0.0;
+        LP<ST> ppAik2 = ppAkk;
+        double sum2 = 0.0;
         const double inv_eta = 1. / eta;
         for (int i = k; i < nr; i++) {
             *ppAik2 *= inv_eta;
@@ -519,7 +578,8 @@ __device__ void qr_solve(double *pA, double *pb, double *pX)
         A1[k] = sigma * *ppAkk;
         A2[k] = -eta * sigma;
         for (int j = k + 1; j < nc; j++) {
-            double *ppAik = ppAkk, sum = 0;
+            LP<ST> ppAik = ppAkk;
+            double sum = 0;
             for (int i = k; i < nr; i++) {
                 sum += *ppAik * ppAik[j - k];
                 ppAik += nc;
@@ -533,9 +593,10 @@ __device__ void qr_solve(double *pA, double *pb, double *pX)
         }
         ppAkk += nc + 1;
     }
-    double *ppAjj = pA;
+    LP<ST> ppAjj = pA;
     for (int j = 0; j < nc; j++) {
-        double *ppAij = ppAjj, tau = 0;
+        LP<ST> ppAij = ppAjj;
+        double tau = 0;
         for (int i = j; i < nr; i++) {
             tau += *ppAij * pb[i];
             ppAij += nc;
@@ -550,7 +611,8 @@ __device__ void qr_solve(double *pA, double *pb, double *pX)
     }
     pX[nc - 1] = pb[nc - 1] / A2[nc - 1];
     for (int i = nc - 2; i >= 0; i--) {
-        double *ppAij = pA + i * nc + (i + 1), sum = 0;
+        LP<ST> ppAij = pA + (i * nc + (i + 1));
+        double sum = 0;
         for (int j = i + 1; j < nc; j++) {
             sum += *ppAij * pX[j];
             ppAij++;
@@ -559,13 +621,14 @@ __device__ void qr_solve(double *pA, double *pb, double *pX)
     }
 }
 
-__device__ void gauss_newton(EpnpLds &S, const double *rho, double *bt)
+template <int ST>
+__device__ void gauss_newton(const EpnpLds<ST> &S, const double *rho, double *bt)
 {
     double b[6], x[4] = {0, 0, 0, 0};
     for (int it = 0; it < 5; it++) {
         for (int i = 0; i < 6; i++) {
-            const double *rowL = S.l + i * 10;
-            double *rowA = S.ga + i * 4;
+            const LP<ST> rowL = S.l + i * 10;
+            const LP<ST> rowA = S.ga + i * 4;
             rowA[0] = 2 * rowL[0] * bt[0] + rowL[1] * bt[1] + rowL[3] * bt[2] + rowL[6] * bt[3];
             rowA[1] = rowL[1] * bt[0] + 2 * rowL[2] * bt[1] + rowL[4] * bt[2] + rowL[7] * bt[3];
             rowA[2] = rowL[3] * bt[0] + rowL[4] * bt[1] + 2 * rowL[5] * bt[2] + rowL[8] * bt[3];
@@ -583,14 +646,15 @@ __device__ void gauss_newton(EpnpLds &S, const double *rho, double *bt)
 }
 
 // compute_ccs, compute_pcs, solve_for_sign, estimate_R_and_t, reprojection_error.
-__device__ double compute_R_and_t(const Points &P, EpnpState &e, EpnpLds &S, const double *betas,
-                                  double R[3][3], double t[3])
+template <int ST>
+__device__ double compute_R_and_t(const Points &P, EpnpState &e, const EpnpLds<ST> &S,
+                                  const double *betas, double R[3][3], double t[3])
 {
     const int n = P.n;
     for (int i = 0; i < 4; i++)
         e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0f;
     for (int i = 0; i < 4; i++) {
-        const double *v = S.ut + 12 * (11 - i);
+        const LP<ST> v = S.ut + 12 * (11 - i);
         for (int j = 0; j < 4; j++)
             for (int k = 0; k < 3; k++)
                 e.ccs[j][k] += betas[i] * v[3 * j + k];
@@ -666,14 +730,22 @@ __device__ double compute_R_and_t(const Points &P, EpnpState &e, EpnpLds &S, con
 }
 
 // epnp::compute_pose on the correspondences P.
-__device__ void epnp_pose(const Points &P, EpnpLds &S, double R[3][3], double t[3])
+template <int ST>
+__device__ void epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3], double t[3])
 {
     EpnpState e;
+    PNP_STAMP(0);
     choose_control_points(P, e, S);
+    PNP_STAMP(1);
     compute_basis_inverse(e, S);
+    PNP_STAMP(2);
     accumulate_mtm(P, e, S);
-    jacobi_svd(S.ut, 12, S.w, S.vt, 12, 12, 12); // MtM is symmetric: its transpose is itself
+    PNP_STAMP(3);
+    // MtM is symmetric, so it is its own transposed copy; EPnP reads only U
+    jacobi_svd<ST, false>(S.ut, 12, S.w, S.w, 0, 12, 12);
+    PNP_STAMP(4);
     compute_L_6x10(S.ut, S.l);
+    PNP_STAMP(5);
     double rho[6];
     rho[0] = dist2(e.cws[0], e.cws[1]);
     rho[1] = dist2(e.cws[0], e.cws[2]);
@@ -685,8 +757,11 @@ __device__ void epnp_pose(const Points &P, EpnpLds &S, double R[3][3], double t[
     for (int c = 1; c <= 3; c++) {
         double betas[4], Rc[3][3], tc[3];
         find_betas_approx(c, S, rho, betas);
+        PNP_STAMP(6 + 3 * (c - 1));
         gauss_newton(S, rho, betas);
+        PNP_STAMP(7 + 3 * (c - 1));
         const double err = compute_R_and_t(P, e, S, betas, Rc, tc);
+        PNP_STAMP(8 + 3 * (c - 1));
         // N = 1; if (err2 < err1) N = 2; if (err3 < err[N]) N = 3
         if (c == 1 || err < best_err) {
             best_err = err;
@@ -700,7 +775,8 @@ __device__ void epnp_pose(const Points &P, EpnpLds &S, double R[3][3], double t[
 }
 
 // cv::Rodrigues matrix -> vector (R re-orthonormalised by SVD first).
-__device__ void rodrigues_mat_to_vec(EpnpLds &S, const double Rin[3][3], double r[3])
+template <int ST>
+__device__ void rodrigues_mat_to_vec(const EpnpLds<ST> &S, const double Rin[3][3], double r[3])
 {
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
@@ -807,33 +883,48 @@ __device__ inline Points make_points(const float *obj, const float *img, const i
 
 } // namespace
 
-// One workgroup (one wave) per hypothesis h: EPnP on rows subsets[5h .. 5h+5),
-// model (rvec, tvec) -> models[6h..], inlier count over all n rows -> counts[h].
-__global__ __launch_bounds__(64) void ransac_hypotheses_kernel(
-    const float *__restrict__ obj, const float *__restrict__ img, int n, CameraK K,
-    const int32_t *__restrict__ subsets, int n_hyp, float thr2, double *__restrict__ models,
-    int32_t *__restrict__ counts)
+// Solve kernel: lane l < HPW of workgroup b solves hypothesis h = b*HPW + l (EPnP
+// on rows subsets[5h .. 5h+5)) and writes its model (rvec, tvec) to models[6h..].
+// Dynamic LDS: HPW * LDS_DOUBLES doubles.
+template <int HPW>
+__global__ __launch_bounds__(64) void ransac_solve_kernel(const float *__restrict__ obj,
+                                                          const float *__restrict__ img, CameraK K,
+                                                          const int32_t *__restrict__ subsets,
+                                                          int n_hyp, double *__restrict__ models)
 {
-    __shared__ EpnpLds S;
-    const int h = blockIdx.x;
+    extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    if (lane == 0) {
-        const Points P = make_points(obj, img, subsets + (int64_t)h * 5, 5, K);
-        double R[3][3], t[3], r[3];
-        epnp_pose(P, S, R, t);
-        rodrigues_mat_to_vec(S, R, r);
-        S.out[0] = r[0]; S.out[1] = r[1]; S.out[2] = r[2];
-        S.out[3] = t[0]; S.out[4] = t[1]; S.out[5] = t[2];
-        rodrigues_vec_to_mat(r, S.out + 6);
-        for (int i = 0; i < 6; i++)
-            models[(int64_t)h * 6 + i] = S.out[i];
-    }
-    __syncthreads();
-    double Rm[9], tv[3];
-    for (int i = 0; i < 9; i++)
-        Rm[i] = S.out[6 + i];
-    for (int i = 0; i < 3; i++)
-        tv[i] = S.out[3 + i];
+    const int h = blockIdx.x * HPW + lane;
+    if (lane >= HPW || h >= n_hyp)
+        return;
+    const EpnpLds<HPW> S(lds + lane);
+    const Points P = make_points(obj, img, subsets + (int64_t)h * 5, 5, K);
+    double R[3][3], t[3], r[3];
+    epnp_pose(P, S, R, t);
+    rodrigues_mat_to_vec(S, R, r);
+    PNP_STAMP(15);
+    double *m = models + (int64_t)h * 6;
+    m[0] = r[0]; m[1] = r[1]; m[2] = r[2];
+    m[3] = t[0]; m[4] = t[1]; m[5] = t[2];
+}
+
+// Scoring kernel: one wavefront per hypothesis (4 per workgroup); lanes stride
+// over the n correspondences, inlier count by ballot + popcount.
+__global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restrict__ obj,
+                                                           const float *__restrict__ img, int n,
+                                                           CameraK K,
+                                                           const double *__restrict__ models,
+                                                           int n_hyp, float thr2,
+                                                           int32_t *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= n_hyp)
+        return;
+    const double *m = models + (int64_t)h * 6;
+    const double r[3] = {m[0], m[1], m[2]}, tv[3] = {m[3], m[4], m[5]};
+    double Rm[9];
+    rodrigues_vec_to_mat(r, Rm);
     int good = 0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
@@ -865,25 +956,58 @@ __global__ __launch_bounds__(64) void epnp_solve_kernel(const float *__restrict_
                                                         const int32_t *__restrict__ idx, int n,
                                                         CameraK K, double *__restrict__ model)
 {
-    __shared__ EpnpLds S;
-    if (threadIdx.x == 0) {
-        const Points P = make_points(obj, img, idx, n, K);
-        double R[3][3], t[3], r[3];
-        epnp_pose(P, S, R, t);
-        rodrigues_mat_to_vec(S, R, r);
-        model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
-        model[3] = t[0]; model[4] = t[1]; model[5] = t[2];
+    __shared__ double lds1[LDS_DOUBLES];
+    if (threadIdx.x != 0)
+        return;
+    const EpnpLds<1> S(lds1);
+    const Points P = make_points(obj, img, idx, n, K);
+    double R[3][3], t[3], r[3];
+    epnp_pose(P, S, R, t);
+    rodrigues_mat_to_vec(S, R, r);
+    model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
+    model[3] = t[0]; model[4] = t[1]; model[5] = t[2];
+}
+
+template <int HPW>
+static hipError_t launch_solve(const float *d_obj, const float *d_img, CameraK K,
+                               const int32_t *d_subsets, int n_hyp, double *d_models,
+                               hipStream_t stream)
+{
+    const size_t lds_bytes = (size_t)HPW * LDS_DOUBLES * sizeof(double);
+    static bool configured = false; // opt in to > 64 KiB of dynamic LDS once per process
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)ransac_solve_kernel<HPW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess)
+            return e;
+        configured = true;
     }
+    ransac_solve_kernel<HPW><<<(n_hyp + HPW - 1) / HPW, 64, lds_bytes, stream>>>(
+        d_obj, d_img, K, d_subsets, n_hyp, d_models);
+    return hipGetLastError();
 }
 
 hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int n, CameraK K,
                                     const int32_t *d_subsets, int n_hyp, float thr2,
-                                    double *d_models, int32_t *d_counts, hipStream_t stream)
+                                    double *d_models, int32_t *d_counts, int n_cus,
+                                    hipStream_t stream)
 {
     if (n_hyp <= 0)
         return hipSuccess;
-    ransac_hypotheses_kernel<<<n_hyp, 64, 0, stream>>>(d_obj, d_img, n, K, d_subsets, n_hyp, thr2,
-                                                       d_models, d_counts);
+    // Hypotheses per wave: few hypotheses -> 16 per wave (4 waves per CU, one
+    // per SIMD, as many CUs as possible); many -> 64 per wave (all lanes busy).
+    hipError_t e;
+    if (n_hyp <= n_cus * 4 * 16)
+        e = launch_solve<16>(d_obj, d_img, K, d_subsets, n_hyp, d_models, stream);
+    else if (n_hyp <= n_cus * 2 * 32)
+        e = launch_solve<32>(d_obj, d_img, K, d_subsets, n_hyp, d_models, stream);
+    else
+        e = launch_solve<64>(d_obj, d_img, K, d_subsets, n_hyp, d_models, stream);
+    if (e != hipSuccess)
+        return e;
+    ransac_score_kernel<<<(n_hyp + 3) / 4, 256, 0, stream>>>(d_obj, d_img, n, K, d_models, n_hyp,
+                                                             thr2, d_counts);
     return hipGetLastError();
 }
 

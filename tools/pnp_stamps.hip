@@ -1,0 +1,53 @@
+// Per-phase cycle counts of one RANSAC-EPnP hypothesis (wave 0), for tuning.
+// build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -DPNP_STAMPS -Iposeestimation_amd/csrc tools/pnp_stamps.hip -o tools/pnp_stamps
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <random>
+#include <vector>
+__device__ long long g_pnp_stamps[32];
+#include "../poseestimation_amd/csrc/ransac_epnp.hip"
+using namespace posehip;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
+int main(int argc, char **argv)
+{
+    const int n = 2000, H = argc > 1 ? atoi(argv[1]) : 4096;
+    std::mt19937_64 rng(3);
+    std::uniform_real_distribution<double> U(-1, 1);
+    std::normal_distribution<double> N(0, 1);
+    const double f = 300.0 / std::tan(22.5 * M_PI / 180), ang = 0.6;
+    std::vector<float> obj(3 * n), img(2 * n);
+    for (int i = 0; i < n; i++) {
+        double X = U(rng), Y = 1.2934 * U(rng), Z = 0.41149 * U(rng);
+        double x = std::cos(ang) * X + std::sin(ang) * Z, y = Y, z = -std::sin(ang) * X + std::cos(ang) * Z + 6;
+        obj[3 * i] = X; obj[3 * i + 1] = Y; obj[3 * i + 2] = Z;
+        bool out = (rng() % 10) < 3;
+        img[2 * i] = out ? 400 + 400 * U(rng) : x / z * f + 400 + N(rng);
+        img[2 * i + 1] = out ? 300 + 300 * U(rng) : y / z * f + 300 + N(rng);
+    }
+    std::vector<int32_t> sub(5 * H);
+    for (int h = 0; h < H; h++) for (int k = 0; k < 5; k++) sub[5 * h + k] = (int)(rng() % n);
+    float *d_obj, *d_img; int32_t *d_sub, *d_counts; double *d_models;
+    CK(hipMalloc(&d_obj, obj.size() * 4)); CK(hipMalloc(&d_img, img.size() * 4)); CK(hipMalloc(&d_sub, sub.size() * 4));
+    CK(hipMalloc(&d_counts, H * 4)); CK(hipMalloc(&d_models, H * 48));
+    CK(hipMemcpy(d_obj, obj.data(), obj.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_img, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_sub, sub.data(), sub.size() * 4, hipMemcpyHostToDevice));
+    CameraK K{f, f, 400, 300};
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < 3; r++) {
+        CK(hipEventRecord(e0));
+        CK(ransac_hypotheses_launch(d_obj, d_img, n, K, d_sub, H, 64.f, d_models, d_counts, 256, 0));
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("H=%d: %.3f ms -> %.3g hyps/s\n", H, ms, H / (ms * 1e-3));
+    }
+    long long st[32];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pnp_stamps), sizeof(st)));
+    const char *names[] = {"", "control points", "basis inverse", "MtM", "jacobi 12x12", "L_6x10", "betas1", "gn1", "Rt1", "betas2", "gn2", "Rt2", "betas3", "gn3", "Rt3", "rodrigues"};
+    for (int k = 1; k <= 15; k++) printf("%-16s %9lld cycles\n", names[k], st[k] - st[k - 1]);
+    printf("total            %9lld cycles\n", st[15] - st[0]);
+    std::vector<int32_t> c(H); CK(hipMemcpy(c.data(), d_counts, H * 4, hipMemcpyDeviceToHost));
+    int mx = 0; for (int v : c) mx = v > mx ? v : mx;
+    printf("max count %d\n", mx);
+    return 0;
+}

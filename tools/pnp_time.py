@@ -1,0 +1,28 @@
+"""Times the RANSAC-EPnP hypothesis kernel (4096 hypotheses x 2000 correspondences)."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import datagen, oracle_bind as orc
+from poseestimation_amd import _lib
+_lib.init(0); lib = _lib.load()
+n, H = 2000, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+obj, img, R, t, inl = datagen.pnp_scene(n=n, seed=3)
+subsets = orc.ransac_subsets(n, H)
+dev = torch.device("cuda", 0)
+d_obj, d_img, d_sub = (torch.from_numpy(x).to(dev) for x in (obj, img, subsets))
+d_models = torch.zeros((H, 6), dtype=torch.float64, device=dev); d_counts = torch.zeros(H, dtype=torch.int32, device=dev)
+K = np.ascontiguousarray(datagen.CAMERA_K).reshape(9); Kp = K.ctypes.data_as(C.POINTER(C.c_double))
+st = torch.cuda.Stream(); torch.cuda.set_stream(st); sp = C.c_void_p(st.cuda_stream); assert st.cuda_stream != 0
+def run():
+    _lib.check(lib.ph_ransac_epnp_hypotheses_dev(d_obj.data_ptr(), d_img.data_ptr(), n, Kp, d_sub.data_ptr(), H, 8.0, d_models.data_ptr(), d_counts.data_ptr(), sp))
+for _ in range(3): run()
+torch.cuda.synchronize()
+ts = []
+for _ in range(10):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); run(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1))
+ms = float(np.median(ts))
+print({"n_hyp": H, "n_points": n, "ms_median": ms, "ms_min": min(ts), "hyps_per_s": H / (ms * 1e-3)})
+t0 = time.perf_counter(); m, c = orc.pnp_hypotheses(obj, img, datagen.CAMERA_K, subsets[:1024], threads=16); dt = time.perf_counter() - t0
+print({"cpu_threads": 16, "cpu_hyps_per_s": 1024 / dt, "counts_equal": bool(np.array_equal(c, d_counts.cpu().numpy()[:1024]))})
