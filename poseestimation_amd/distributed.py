@@ -1,0 +1,96 @@
+"""One-process-per-GPU partitioning of the matcher (torch.distributed; backend
+"nccl" is RCCL on ROCm).
+
+Two modes, neither of which exists in the reference (it is single-process):
+
+frame batch   independent frames against one replicated train set: frames are
+              dealt to ranks in contiguous blocks and nothing is exchanged.
+train shards  one large train set split into contiguous row ranges, one per
+              rank; every rank searches all queries in its range (emitting
+              GLOBAL train indices), the per-shard k-best lists are all-gathered
+              (the one exchange step) and every rank merges them.  Shards are
+              gathered in rank order = ascending index order, and the merge key is
+              (distance, global index), so OpenCV's lowest-index tie-break holds
+              across shards.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def block_bounds(n, parts, part):
+    """Contiguous block `part` of `n` items dealt to `parts` owners: [lo, hi)."""
+    if parts < 1 or not 0 <= part < parts:
+        raise ValueError("bad partition")
+    lo = n * part // parts
+    hi = n * (part + 1) // parts
+    return lo, hi
+
+
+def frames_of_rank(n_frames, world, rank):
+    """Frame indices owned by `rank` (contiguous block)."""
+    lo, hi = block_bounds(n_frames, world, rank)
+    return range(lo, hi)
+
+
+def allgather_candidates(cand_idx, cand_dist, group=None):
+    """All-gather of per-shard k-best lists.
+
+    cand_idx, cand_dist: int32 [nq, k] on this rank (global train indices).
+    Returns ([world, nq, k] idx, [world, nq, k] dist), shards in rank order.
+    Works with any backend (RCCL on GPUs, gloo on CPU tensors).
+    """
+    world = dist.get_world_size(group)
+    if cand_idx.dtype != torch.int32 or cand_dist.dtype != torch.int32:
+        raise ValueError("candidate lists must be int32")
+    if cand_idx.shape != cand_dist.shape or cand_idx.dim() != 2:
+        raise ValueError("candidate lists must both be [nq, k]")
+    # one message per rank: idx and dist travel together ([2, nq, k])
+    mine = torch.stack([cand_idx, cand_dist]).contiguous()
+    nq, k = cand_idx.shape
+    gathered = torch.empty((world * 2, nq, k), dtype=torch.int32, device=mine.device)
+    dist.all_gather_into_tensor(gathered, mine, group=group)  # concatenates along dim 0
+    gathered = gathered.view(world, 2, nq, k)
+    return gathered[:, 0].contiguous(), gathered[:, 1].contiguous()
+
+
+def _stream_ptr():
+    s = torch.cuda.current_stream().cuda_stream
+    return C.c_void_p(s) if s else None
+
+
+def knn_train_sharded(d_query, d_train_shard, shard_base, k, ratio=None, group=None):
+    """k-NN of all queries against a train set sharded over the ranks of `group`.
+
+    d_query: uint8 [nq, 32] on this rank's GPU (the same queries on every rank);
+    d_train_shard: uint8 [nt_local, 32], rows [shard_base, shard_base + nt_local)
+    of the global train set.  Returns (idx [nq, k], dist [nq, k], keep [nq] or
+    None) as GPU tensors, identical on every rank.
+    """
+    lib = _lib.load()
+    nq, nt = d_query.shape[0], d_train_shard.shape[0]
+    dev = d_query.device
+    idx = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    dst = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    # kernels run on torch's current stream so the collective that follows is ordered
+    # after them without a host sync
+    sp = _stream_ptr()
+    if sp is None:
+        raise RuntimeError("run under `with torch.cuda.stream(torch.cuda.Stream())`: torch's "
+                           "default stream has no handle to pass through the C ABI")
+    _lib.check(lib.ph_knn_hamming256_dev(d_query.data_ptr(), nq, d_train_shard.data_ptr(), nt, k,
+                                         int(shard_base), idx.data_ptr(), dst.data_ptr(), None,
+                                         0.0, sp))
+    all_idx, all_dst = allgather_candidates(idx, dst, group)
+    world = all_idx.shape[0]
+    out_idx = torch.empty_like(idx)
+    out_dst = torch.empty_like(dst)
+    keep = torch.empty(nq, dtype=torch.uint8, device=dev) if ratio is not None else None
+    _lib.check(lib.ph_knn_merge_dev(all_idx.data_ptr(), all_dst.data_ptr(), world, nq, k,
+                                    out_idx.data_ptr(), out_dst.data_ptr(),
+                                    keep.data_ptr() if keep is not None else None,
+                                    float(ratio) if ratio is not None else 0.0, sp))
+    return out_idx, out_dst, keep

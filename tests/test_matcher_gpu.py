@@ -175,3 +175,128 @@ def test_python_mirror_matches_reference_script_flow(posehip):
     ridx, rdist = orc.knn(des1, des2, 2)
     assert [[m.trainIdx for m in r] for r in rows2] == ridx.tolist()
     assert [[m.distance for m in r] for r in rows2] == rdist.astype(float).tolist()
+
+
+# ---- device-buffer entry points ------------------------------------------------
+def _dev(arr):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(arr)).to("cuda:0")
+
+
+def gpu_knn_dev(lib, d_q, d_t, k, base=0, ratio=None):
+    import torch
+    nq, nt = d_q.shape[0], d_t.shape[0]
+    idx = torch.full((nq, k), 777, dtype=torch.int32, device="cuda:0")
+    dist = torch.full((nq, k), 777, dtype=torch.int32, device="cuda:0")
+    keep = torch.full((nq,), 9, dtype=torch.uint8, device="cuda:0") if ratio is not None else None
+    torch.cuda.synchronize()
+    lib.check(lib.load().ph_knn_hamming256_dev(
+        d_q.data_ptr() if nq else None, nq, d_t.data_ptr() if nt else None, nt, k, base,
+        idx.data_ptr(), dist.data_ptr(), keep.data_ptr() if keep is not None else None,
+        ratio if ratio is not None else 0.0, None))
+    lib.check(lib.load().ph_stream_synchronize(None))
+    return idx, dist, keep
+
+
+def test_full_size_config_bit_exact(posehip):
+    """BASELINE configs[1] at full size: 10k x 10k, k=2 + ratio, every row checked."""
+    q = datagen.random_descriptors(10000, 2)
+    t = datagen.random_descriptors(10000, 102)
+    idx, dist, keep = gpu_knn_dev(posehip, _dev(q), _dev(t), 2, ratio=0.75)
+    ridx, rdist = orc.knn(q, t, 2, threads=8)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(dist.cpu().numpy(), rdist)
+    kept = [m[0] for m in orc.ratio_filter(ridx, rdist, 0.75)]
+    assert np.nonzero(keep.cpu().numpy())[0].tolist() == kept
+
+
+def test_long_train_stream_sampled(posehip):
+    """200k queries x 60k train rows (the lazy key-update path, several rows per wave
+    slice): 512 sampled query rows checked against the oracle, plus properties that
+    hold for every row."""
+    q = datagen.random_descriptors(200_000, 7)
+    t = np.concatenate([datagen.random_descriptors(59_000, 8), q[:1000]])  # exact hits exist
+    idx, dist, _ = gpu_knn_dev(posehip, _dev(q), _dev(t), 2)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    rows = np.random.default_rng(0).choice(200_000, 512, replace=False)
+    rows[:8] = np.arange(8)  # rows with an exact copy in the train set
+    ridx, rdist = orc.knn(q[rows], t, 2, threads=8)
+    assert np.array_equal(idx[rows], ridx) and np.array_equal(dist[rows], rdist)
+    assert (dist[:1000, 0] == 0).all() and (idx[:1000, 0] == 59_000 + np.arange(1000)).all()
+    assert (dist[:, 0] <= dist[:, 1]).all() and (idx[:, 0] != idx[:, 1]).all()
+    assert idx.min() >= 0 and idx.max() < 60_000
+    # reported distances are the true distances of the reported rows
+    sel = np.random.default_rng(1).choice(200_000, 4096, replace=False)
+    for r in range(2):
+        true = np.unpackbits(q[sel] ^ t[idx[sel, r]], axis=1).sum(axis=1)
+        assert np.array_equal(true, dist[sel, r])
+
+
+@pytest.mark.parametrize("n_shards,k", [(2, 2), (3, 1), (8, 2)])
+def test_shard_merge(posehip, n_shards, k):
+    """Train set split into contiguous shards, searched shard by shard with global
+    indices, merged on the GPU: equals the unsharded search (lowest index on ties)."""
+    import torch
+    from poseestimation_amd.distributed import block_bounds
+    q = datagen.codebook_descriptors(700, 51, words=32)
+    t = datagen.codebook_descriptors(2000, 52, words=32)
+    d_q = _dev(q)
+    ci, cd = [], []
+    for s in range(n_shards):
+        lo, hi = block_bounds(2000, n_shards, s)
+        i, d, _ = gpu_knn_dev(posehip, d_q, _dev(t[lo:hi]), k, base=lo)
+        ci.append(i)
+        cd.append(d)
+    all_i, all_d = torch.stack(ci).contiguous(), torch.stack(cd).contiguous()
+    out_i = torch.empty((700, k), dtype=torch.int32, device="cuda:0")
+    out_d = torch.empty((700, k), dtype=torch.int32, device="cuda:0")
+    keep = torch.empty(700, dtype=torch.uint8, device="cuda:0") if k == 2 else None
+    torch.cuda.synchronize()
+    posehip.check(posehip.load().ph_knn_merge_dev(
+        all_i.data_ptr(), all_d.data_ptr(), n_shards, 700, k, out_i.data_ptr(), out_d.data_ptr(),
+        keep.data_ptr() if keep is not None else None, 0.8, None))
+    posehip.check(posehip.load().ph_stream_synchronize(None))
+    ridx, rdist = orc.knn(q, t, k)
+    assert np.array_equal(out_i.cpu().numpy(), ridx)
+    assert np.array_equal(out_d.cpu().numpy(), rdist)
+    if k == 2:
+        kept = [m[0] for m in orc.ratio_filter(ridx, rdist, 0.8)]
+        assert np.nonzero(keep.cpu().numpy())[0].tolist() == kept
+
+
+def test_train_sharded_world1(posehip):
+    """knn_train_sharded end to end in a one-rank group on the GPU."""
+    import torch
+    import torch.distributed as dist
+    from poseestimation_amd.distributed import knn_train_sharded
+    q = datagen.random_descriptors(900, 61)
+    t = datagen.random_descriptors(1300, 62)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1)
+        created = True
+    try:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            idx, dst, keep = knn_train_sharded(_dev(q), _dev(t), 0, 2, ratio=0.75)
+            torch.cuda.current_stream().synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    ridx, rdist = orc.knn(q, t, 2)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dst.cpu().numpy(), rdist)
+
+
+def test_crosscheck_dev(posehip):
+    import torch
+    q = datagen.random_descriptors(3000, 71)
+    t = datagen.perturbed_copy(q, 72)[:2500]
+    d_q, d_t = _dev(q), _dev(t)
+    idx = torch.empty(3000, dtype=torch.int32, device="cuda:0")
+    dist = torch.empty(3000, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    posehip.check(posehip.load().ph_match_crosscheck_hamming256_dev(
+        d_q.data_ptr(), 3000, d_t.data_ptr(), 2500, idx.data_ptr(), dist.data_ptr(), None))
+    posehip.check(posehip.load().ph_stream_synchronize(None))
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    got = [(int(i), int(idx[i]), 0, float(dist[i])) for i in range(3000) if idx[i] >= 0]
+    assert got == orc.match(q, t, cross_check=True)
