@@ -1,0 +1,229 @@
+// posehip.hpp -- C++17 shim over the C ABI of posehip.h that keeps the call
+// signatures of the OpenCV classes the reference uses on its hot path, so that
+// the reference's call sites change by a type name only:
+//
+//   src/cereal_box.cpp:53    Ptr<DescriptorMatcher> matcher = DescriptorMatcher::create("BruteForce-Hamming");
+//                         -> auto matcher = posehip::DescriptorMatcher::create("BruteForce-Hamming");
+//   src/cereal_box.cpp:344   matcher->match(descriptors, descriptorsOld, matches);      (unchanged)
+//   src/orb_feature_matching/matcher.py:18,21  BFMatcher(NORM_HAMMING, crossCheck=true).match(des1, des2)
+//   EPnP branch (docs/index.md:75,120)  solvePnPRansac(obj, img, K, dist, rvec, tvec, false, iters, err, conf, inliers, SOLVEPNP_EPNP)
+//
+// The header needs no OpenCV.  Define POSEHIP_WITH_OPENCV before including it
+// (with <opencv2/core.hpp> on the include path) to get overloads that take
+// cv::Mat / std::vector<cv::DMatch> directly.  Errors: the C ABI never throws;
+// this shim converts a non-zero status into posehip::Error (the reference lets
+// cv::Exception propagate the same way).
+#ifndef POSEHIP_HPP
+#define POSEHIP_HPP
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "posehip.h"
+
+#ifdef POSEHIP_WITH_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+namespace posehip {
+
+struct Error : std::runtime_error {
+    ph_status status;
+    Error(ph_status s, const char *msg) : std::runtime_error(msg), status(s) {}
+};
+
+inline void check(ph_status s)
+{
+    if (s != PH_OK)
+        throw Error(s, ph_last_error_string());
+}
+
+// cv::DMatch, field for field (16 bytes).
+struct DMatch {
+    int queryIdx = -1;
+    int trainIdx = -1;
+    int imgIdx = -1;
+    float distance = 3.402823466e+38f;
+    DMatch() = default;
+    DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(-1), distance(d) {}
+    DMatch(int q, int t, int i, float d) : queryIdx(q), trainIdx(t), imgIdx(i), distance(d) {}
+    bool operator<(const DMatch &m) const { return distance < m.distance; }
+};
+static_assert(sizeof(DMatch) == sizeof(ph_dmatch), "DMatch must match the C ABI layout");
+
+// What the matcher needs of a cv::Mat of ORB descriptors: CV_8UC1, 32 columns.
+struct Descriptors {
+    const std::uint8_t *data = nullptr;
+    int rows = 0;
+    std::size_t step = 32; // bytes between rows (cv::Mat::step)
+    Descriptors() = default;
+    Descriptors(const std::uint8_t *d, int r, std::size_t s = 32) : data(d), rows(r), step(s) {}
+#ifdef POSEHIP_WITH_OPENCV
+    Descriptors(const cv::Mat &m) // NOLINT: implicit, like cv::InputArray
+        : data(m.data), rows(m.rows), step(m.empty() ? 32 : (std::size_t)m.step)
+    {
+        if (!m.empty() && (m.type() != CV_8UC1 || m.cols != 32))
+            throw Error(PH_ERR_INVALID_ARG, "descriptors must be CV_8UC1 with 32 columns (ORB)");
+    }
+#endif
+};
+
+enum NormTypes { NORM_HAMMING = 6 };
+enum SolvePnPMethod { SOLVEPNP_EPNP = 1 };
+
+// cv::BFMatcher / cv::DescriptorMatcher for NORM_HAMMING on 256-bit descriptors.
+class BFMatcher {
+  public:
+    explicit BFMatcher(int normType = NORM_HAMMING, bool crossCheck = false, int device = 0)
+        : crossCheck_(crossCheck)
+    {
+        if (normType != NORM_HAMMING)
+            throw Error(PH_ERR_INVALID_ARG, "only NORM_HAMMING is implemented");
+        if (ph_device() < 0)
+            check(ph_init(device));
+    }
+
+    // DescriptorMatcher::match(query, train, matches): src/cereal_box.cpp:344.
+    void match(const Descriptors &query, const Descriptors &train, std::vector<DMatch> &matches) const
+    {
+        matches.clear();
+        if (query.rows == 0 || train.rows == 0)
+            return;
+        matches.resize((std::size_t)query.rows);
+        int n = 0;
+        auto *out = reinterpret_cast<ph_dmatch *>(matches.data());
+        check(crossCheck_ ? ph_match_crosscheck_hamming256(query.data, query.rows, query.step, train.data,
+                                                           train.rows, train.step, out, &n)
+                          : ph_match_hamming256(query.data, query.rows, query.step, train.data, train.rows,
+                                                train.step, out, &n));
+        matches.resize((std::size_t)n);
+    }
+
+    // DescriptorMatcher::knnMatch(query, train, matches, k), k = 1 or 2.
+    void knnMatch(const Descriptors &query, const Descriptors &train, std::vector<std::vector<DMatch>> &matches,
+                  int k) const
+    {
+        matches.clear();
+        if (crossCheck_) { // BFMatcher asserts K == 1 with crossCheck
+            if (k != 1)
+                throw Error(PH_ERR_INVALID_ARG, "crossCheck requires k == 1");
+            std::vector<DMatch> flat;
+            match(query, train, flat);
+            for (const DMatch &m : flat)
+                matches.push_back({m});
+            return;
+        }
+        if (query.rows == 0 || train.rows == 0)
+            return;
+        std::vector<std::int32_t> idx((std::size_t)query.rows * k), dist((std::size_t)query.rows * k);
+        check(ph_knn_hamming256(query.data, query.rows, query.step, train.data, train.rows, train.step, k,
+                                idx.data(), dist.data()));
+        matches.resize((std::size_t)query.rows);
+        for (int i = 0; i < query.rows; i++)
+            for (int r = 0; r < k && idx[(std::size_t)i * k + r] >= 0; r++)
+                matches[(std::size_t)i].emplace_back(i, idx[(std::size_t)i * k + r], 0,
+                                                     (float)dist[(std::size_t)i * k + r]);
+    }
+
+    bool isCrossCheck() const { return crossCheck_; }
+
+  private:
+    bool crossCheck_;
+};
+
+// DescriptorMatcher::create("BruteForce-Hamming"): src/cereal_box.cpp:53.
+struct DescriptorMatcher {
+    static std::shared_ptr<BFMatcher> create(const std::string &type)
+    {
+        if (type != "BruteForce-Hamming")
+            throw Error(PH_ERR_INVALID_ARG, "only \"BruteForce-Hamming\" is implemented");
+        return std::make_shared<BFMatcher>(NORM_HAMMING, false);
+    }
+};
+
+// knnMatch(k = 2) + Lowe ratio test (benchmark configuration; not in the reference).
+inline void ratioTestMatch(const Descriptors &query, const Descriptors &train, float ratio,
+                           std::vector<DMatch> &good)
+{
+    good.clear();
+    if (query.rows == 0 || train.rows == 0)
+        return;
+    if (ph_device() < 0)
+        check(ph_init(0));
+    good.resize((std::size_t)query.rows);
+    int n = 0;
+    check(ph_knn2_ratio_hamming256(query.data, query.rows, query.step, train.data, train.rows, train.step, ratio,
+                                   reinterpret_cast<ph_dmatch *>(good.data()), &n));
+    good.resize((std::size_t)n);
+}
+
+// The good_matches filter of src/cereal_box.cpp:345-356 (explicit bounds; the
+// output starts empty instead of growing across frames).
+inline void minDistFilter(const std::vector<DMatch> &matches, std::vector<DMatch> &good)
+{
+    good.resize(matches.size());
+    int n = 0;
+    check(ph_min_dist_filter(reinterpret_cast<const ph_dmatch *>(matches.data()), (int)matches.size(),
+                             reinterpret_cast<ph_dmatch *>(good.data()), &n));
+    good.resize((std::size_t)n);
+}
+
+struct Point3f {
+    float x, y, z;
+};
+struct Point2f {
+    float x, y;
+};
+
+// cv::solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs = none,
+// rvec, tvec, useExtrinsicGuess = false, iterationsCount = 100,
+// reprojectionError = 8.0, confidence = 0.99, inliers, flags = SOLVEPNP_EPNP).
+// cameraMatrix: row-major 3 x 3.  rvec / tvec: 3 doubles each.
+inline bool solvePnPRansac(const std::vector<Point3f> &objectPoints, const std::vector<Point2f> &imagePoints,
+                           const double cameraMatrix[9], double rvec[3], double tvec[3],
+                           bool useExtrinsicGuess = false, int iterationsCount = 100,
+                           float reprojectionError = 8.0f, double confidence = 0.99,
+                           std::vector<int> *inliers = nullptr, int flags = SOLVEPNP_EPNP)
+{
+    if (flags != SOLVEPNP_EPNP || useExtrinsicGuess)
+        throw Error(PH_ERR_INVALID_ARG, "only SOLVEPNP_EPNP without an extrinsic guess is implemented");
+    if (objectPoints.size() != imagePoints.size())
+        throw Error(PH_ERR_INVALID_ARG, "objectPoints and imagePoints differ in length");
+    if (ph_device() < 0)
+        check(ph_init(0));
+    const int n = (int)objectPoints.size();
+    std::vector<std::int32_t> inl((std::size_t)n);
+    int n_inl = 0, found = 0;
+    check(ph_solvepnp_ransac_epnp(&objectPoints[0].x, &imagePoints[0].x, n, cameraMatrix, iterationsCount,
+                                  reprojectionError, confidence, 0xFFFFFFFFFFFFFFFFull, rvec, tvec, inl.data(),
+                                  &n_inl, &found, nullptr));
+    if (inliers) {
+        if (found)
+            inliers->assign(inl.begin(), inl.begin() + n_inl);
+        else
+            inliers->clear();
+    }
+    return found != 0;
+}
+
+#ifdef POSEHIP_WITH_OPENCV
+// Drop-in overloads on OpenCV's own types.
+inline void match(const BFMatcher &m, const cv::Mat &query, const cv::Mat &train, std::vector<cv::DMatch> &out)
+{
+    std::vector<DMatch> tmp;
+    m.match(Descriptors(query), Descriptors(train), tmp);
+    out.resize(tmp.size());
+    static_assert(sizeof(cv::DMatch) == sizeof(DMatch), "cv::DMatch layout");
+    if (!tmp.empty())
+        std::memcpy(static_cast<void *>(out.data()), tmp.data(), tmp.size() * sizeof(DMatch));
+}
+#endif
+
+} // namespace posehip
+
+#endif // POSEHIP_HPP
