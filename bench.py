@@ -50,24 +50,40 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
     H, n, P = args.ransac_hyps, args.ransac_points, args.ransac_problems
     K = np.ascontiguousarray(datagen.CAMERA_K).reshape(9)
     Kp = K.ctypes.data_as(C.POINTER(C.c_double))
-    probs = []
+    objs, imgs, subs = [], [], []
     for p in range(P):
         obj, img, R, t, inl = datagen.pnp_scene(n=n, outlier_frac=0.3, seed=3 + p + 100 * rank)
         sub = np.empty((H, 5), np.int32)
         _lib.check(lib.ph_ransac_subsets(0xFFFFFFFFFFFFFFFF, n, H,
                                          sub.ctypes.data_as(C.POINTER(C.c_int32))))
-        probs.append((obj, img, sub, torch.from_numpy(obj).to(dev), torch.from_numpy(img).to(dev),
-                      torch.from_numpy(sub).to(dev),
-                      torch.empty((H, 6), dtype=torch.float64, device=dev),
-                      torch.empty(H, dtype=torch.int32, device=dev)))
+        objs.append(obj)
+        imgs.append(img)
+        subs.append(sub)
+    # the P problems (frames) of a step go down in ONE batched launch
+    d_obj = torch.from_numpy(np.concatenate(objs)).to(dev)
+    d_img = torch.from_numpy(np.concatenate(imgs)).to(dev)
+    d_sub = torch.from_numpy(np.concatenate(subs)).to(dev)
+    d_off = torch.arange(0, (P + 1) * n, n, dtype=torch.int32, device=dev)
+    d_m = torch.empty((P * H, 6), dtype=torch.float64, device=dev)
+    d_c = torch.empty(P * H, dtype=torch.int32, device=dev)
 
     def step():
-        for (_, _, _, d_obj, d_img, d_sub, d_m, d_c) in probs:
-            st = lib.ph_ransac_epnp_hypotheses_dev(d_obj.data_ptr(), d_img.data_ptr(), n, Kp,
-                                                   d_sub.data_ptr(), H, 8.0, d_m.data_ptr(),
-                                                   d_c.data_ptr(), sptr)
-            if st != 0:
-                _lib.check(st)
+        _lib.check(lib.ph_ransac_epnp_hypotheses_batched_dev(
+            d_obj.data_ptr(), d_img.data_ptr(), d_off.data_ptr(), P, Kp, d_sub.data_ptr(), H, 8.0,
+            d_m.data_ptr(), d_c.data_ptr(), sptr))
+
+    # latency of a single problem (one call), for reference
+    def one_problem():
+        _lib.check(lib.ph_ransac_epnp_hypotheses_dev(d_obj.data_ptr(), d_img.data_ptr(), n, Kp,
+                                                     d_sub.data_ptr(), H, 8.0, d_m.data_ptr(),
+                                                     d_c.data_ptr(), sptr))
+    one_problem()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        one_problem()
+    torch.cuda.synchronize()
+    single_ms = (time.perf_counter() - t0) / 5 * 1e3
 
     step()
     torch.cuda.synchronize()
@@ -88,10 +104,12 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
     res = {
         "value": float(H) * P * world * args.ransac_steps / el,
         "unit": "hypotheses/s",
-        "ms_per_problem": el / args.ransac_steps / P * 1e3,
+        "ms_per_step": el / args.ransac_steps * 1e3,
+        "single_problem_ms": single_ms,
+        "single_problem_hyps_per_s": H / (single_ms * 1e-3),
         "config": {"workload": f"{H} EPnP hypotheses (5-point samples, fp64) each scored on {n} "
                                f"2D-3D correspondences, 30% outliers (BASELINE configs[2]); "
-                               f"{P} problems per step per GPU, one call per problem",
+                               f"{P} problems per step per GPU in one batched launch",
                    "n_hyp": H, "n_points": n, "problems_per_step": P},
         "dtype": "f64 solve, f32 reprojection error",
     }
@@ -102,13 +120,15 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
         except AttributeError:
             cores = os.cpu_count() or 1
         threads = max(1, min(16, cores))
-        obj, img, sub = probs[0][0], probs[0][1], probs[0][2]
+        obj, img, sub = objs[0], imgs[0], subs[0]
         hs = min(H, 2048)
         c0 = time.perf_counter()
         m, c = orc.pnp_hypotheses(obj, img, datagen.CAMERA_K, sub[:hs], threads=threads)
         dt = time.perf_counter() - c0
-        g_c = probs[0][7].cpu().numpy()[:hs]
-        g_m = probs[0][6].cpu().numpy()[:hs]
+        step()
+        torch.cuda.synchronize()
+        g_c = d_c.cpu().numpy()[:hs]
+        g_m = d_m.cpu().numpy()[:hs]
         res["cpu_baseline"] = {
             "value": hs / dt, "unit": "hypotheses/s", "cores": threads, "kind": "port",
             "sample": f"first {hs} hypotheses of problem 0 (oracle/pnp_ransac.c, {threads} pthreads)",

@@ -171,6 +171,19 @@ ph_status ph_ransac_epnp_hypotheses_dev(const float *d_obj, const float *d_img, 
                                         float reproj_err, double *d_models, int32_t *d_counts,
                                         void *stream);
 
+/* The same for a batch of independent problems (frames) in one launch: problem
+ * p owns correspondence rows [d_point_offsets[p], d_point_offsets[p+1]) of
+ * d_obj / d_img (n_problems + 1 int32 offsets on the device), all problems share
+ * K and have hyp_per_problem hypotheses; d_subsets[(p*hyp_per_problem + h)*5 ..]
+ * index rows RELATIVE to the problem's range; outputs are indexed
+ * p*hyp_per_problem + h.  No counterpart in the reference (it solves one frame
+ * at a time); it exists so that many frames fill the GPU. */
+ph_status ph_ransac_epnp_hypotheses_batched_dev(const float *d_obj, const float *d_img,
+                                                const int32_t *d_point_offsets, int n_problems,
+                                                const double *K, const int32_t *d_subsets,
+                                                int hyp_per_problem, float reproj_err,
+                                                double *d_models, int32_t *d_counts, void *stream);
+
 /* ---- measurement aids (no counterpart in the reference) -------------------- */
 
 /* With profiling on, every k-NN call records HIP events around its distance

@@ -59,6 +59,9 @@ SIGNATURES = {
                                           C.c_double, C.c_uint64, _f64p, _f64p, _i32p, _intp,
                                           _intp, _intp]),
     "ph_solvepnp_epnp": (C.c_int, [_f32p, _f32p, C.c_int, _f64p, _f64p, _f64p]),
+    "ph_ransac_epnp_hypotheses_batched_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                        _f64p, C.c_void_p, C.c_int, C.c_float,
+                                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "ph_ransac_subsets": (C.c_int, [C.c_uint64, C.c_int, C.c_int, _i32p]),
     "ph_ransac_epnp_hypotheses_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _f64p,
                                                 C.c_void_p, C.c_int, C.c_float, C.c_void_p,

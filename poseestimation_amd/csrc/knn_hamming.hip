@@ -12,6 +12,7 @@
 //     8 x v_xor_b32 + 8 x v_bcnt_u32_b32 (accumulating)        = 16 ops
 //   + 1 x v_lshl_add_u32 (key = dist << 22 | local train index)
 //   + 1 x v_min_u32 + 1 x v_med3_u32 (running best / second best) =  3 ops
+// (the median-of-three is dropped for k = 1)
 // Keys order by (distance, train index), so min / median-of-three reproduce
 // the strict-'<' insertion rule exactly.
 //
@@ -77,9 +78,11 @@ __device__ __forceinline__ uint32_t make_key(uint32_t d, uint32_t j)
     return r;
 }
 
-__device__ __forceinline__ void top2_update(uint32_t &m1, uint32_t &m2, uint32_t key)
+// K == 2: running best and second best; K == 1: best only (one VALU op less).
+template <int K> __device__ __forceinline__ void top2_update(uint32_t &m1, uint32_t &m2, uint32_t key)
 {
-    m2 = med3_u32(m1, m2, key);
+    if constexpr (K == 2)
+        m2 = med3_u32(m1, m2, key);
     m1 = min(m1, key);
 }
 
@@ -102,14 +105,14 @@ __device__ __forceinline__ void load_group(RowGroup &g, const Row *__restrict__ 
 // with an equal distance can never enter, by the strict '<' rule), which costs
 // 16 + 3/UNROLL ops per pair plus a wave-uniform branch; it wins once a wave
 // streams enough train rows for candidates to become rare.
-template <bool LAZY>
+template <bool LAZY, int K>
 __device__ __forceinline__ void eval_group(const RowGroup &g, const uint32_t (&q)[8], uint32_t &m1,
                                            uint32_t &m2, uint32_t &thr, uint32_t j)
 {
     if constexpr (!LAZY) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++)
-            top2_update(m1, m2, make_key(hamming256(q, g.r[u]), j + u));
+            top2_update<K>(m1, m2, make_key(hamming256(q, g.r[u]), j + u));
     } else {
         uint32_t d[UNROLL];
 #pragma unroll
@@ -122,8 +125,8 @@ __device__ __forceinline__ void eval_group(const RowGroup &g, const uint32_t (&q
         if (__builtin_amdgcn_ballot_w64(dmin < thr) != 0) {
 #pragma unroll
             for (int u = 0; u < UNROLL; u++)
-                top2_update(m1, m2, make_key(d[u], j + u));
-            thr = m2 >> KNN_KEY_SHIFT;
+                top2_update<K>(m1, m2, make_key(d[u], j + u));
+            thr = (K == 2 ? m2 : m1) >> KNN_KEY_SHIFT;
         }
     }
 }
@@ -141,7 +144,7 @@ template <typename K> __device__ __forceinline__ void merge_pairs(K &a1, K &a2, 
 // (one per lane) and each stream their own slice of the workgroup's train
 // split; the per-wave key pairs are folded through LDS and the workgroup
 // writes one pair per query: part[split][rank 0/1][nq], keys local to the split.
-template <bool LAZY>
+template <bool LAZY, int K>
 __global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_kernel(
     const uint4 *__restrict__ query, const uint4 *__restrict__ train, int64_t nq, int64_t nt,
     int64_t rows_per_split, int rows_per_wave, uint32_t *__restrict__ part)
@@ -179,16 +182,16 @@ __global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_kernel(
     int g = 0;
     for (; g + 1 < n_groups; g += 2) {
         load_group(gb, rows + (g + 1) * UNROLL);
-        eval_group<LAZY>(ga, q, m1, m2, thr, (uint32_t)(w0 + g * UNROLL));
+        eval_group<LAZY, K>(ga, q, m1, m2, thr, (uint32_t)(w0 + g * UNROLL));
         if (g + 2 < n_groups)
             load_group(ga, rows + (g + 2) * UNROLL);
-        eval_group<LAZY>(gb, q, m1, m2, thr, (uint32_t)(w0 + (g + 1) * UNROLL));
+        eval_group<LAZY, K>(gb, q, m1, m2, thr, (uint32_t)(w0 + (g + 1) * UNROLL));
     }
     if (g < n_groups)
-        eval_group<LAZY>(ga, q, m1, m2, thr, (uint32_t)(w0 + g * UNROLL));
+        eval_group<LAZY, K>(ga, q, m1, m2, thr, (uint32_t)(w0 + g * UNROLL));
     for (int j = n_groups * UNROLL; j < n; j++) {
         const Row t = rows[j];
-        top2_update(m1, m2, make_key(hamming256(q, t), (uint32_t)(w0 + j)));
+        top2_update<K>(m1, m2, make_key(hamming256(q, t), (uint32_t)(w0 + j)));
     }
 
     if (n_waves > 1) {
@@ -400,14 +403,20 @@ hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const v
     hipError_t e;
     if (events && (e = hipEventRecord(events[0], stream)) != hipSuccess)
         return e;
-    if (p.lazy)
-        knn_partial_kernel<true><<<grid, p.waves * 64, 0, stream>>>(
-            (const uint4 *)d_query, (const uint4 *)d_train, nq, nt, p.rows_per_split,
-            p.rows_per_wave, d_part);
+    const uint4 *q4 = (const uint4 *)d_query, *t4 = (const uint4 *)d_train;
+    const int threads = p.waves * 64;
+    if (p.lazy && k == 2)
+        knn_partial_kernel<true, 2><<<grid, threads, 0, stream>>>(q4, t4, nq, nt, p.rows_per_split,
+                                                                  p.rows_per_wave, d_part);
+    else if (p.lazy)
+        knn_partial_kernel<true, 1><<<grid, threads, 0, stream>>>(q4, t4, nq, nt, p.rows_per_split,
+                                                                  p.rows_per_wave, d_part);
+    else if (k == 2)
+        knn_partial_kernel<false, 2><<<grid, threads, 0, stream>>>(q4, t4, nq, nt, p.rows_per_split,
+                                                                   p.rows_per_wave, d_part);
     else
-        knn_partial_kernel<false><<<grid, p.waves * 64, 0, stream>>>(
-            (const uint4 *)d_query, (const uint4 *)d_train, nq, nt, p.rows_per_split,
-            p.rows_per_wave, d_part);
+        knn_partial_kernel<false, 1><<<grid, threads, 0, stream>>>(q4, t4, nq, nt, p.rows_per_split,
+                                                                   p.rows_per_wave, d_part);
     if ((e = hipGetLastError()) != hipSuccess)
         return e;
     if (events && (e = hipEventRecord(events[1], stream)) != hipSuccess)

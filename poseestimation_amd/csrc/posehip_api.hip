@@ -636,9 +636,36 @@ ph_status ph_ransac_epnp_hypotheses_dev(const float *d_obj, const float *d_img, 
     if (n < 5 || n_hyp < 0 || (n_hyp > 0 && (!d_subsets || !d_models || !d_counts)))
         return fail(PH_ERR_INVALID_ARG, "need >= 5 correspondences and non-null buffers");
     const double thr = reproj_err;
-    PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, camera_of(K), d_subsets, n_hyp,
+    PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, camera_of(K), d_subsets, nullptr, 1, n_hyp,
                                     (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
                                     pick_stream(stream)));
+    return PH_OK;
+}
+
+ph_status ph_ransac_epnp_hypotheses_batched_dev(const float *d_obj, const float *d_img,
+                                                const int32_t *d_point_offsets, int n_problems,
+                                                const double *K, const int32_t *d_subsets,
+                                                int hyp_per_problem, float reproj_err,
+                                                double *d_models, int32_t *d_counts, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if ((s = check_pnp_args(d_obj, d_img, 1, K)) != PH_OK)
+        return s;
+    if (n_problems < 0 || hyp_per_problem < 0)
+        return fail(PH_ERR_INVALID_ARG, "negative problem or hypothesis count");
+    if ((int64_t)n_problems * hyp_per_problem > 0x7FFFFFFF)
+        return fail(PH_ERR_TOO_LARGE, "more than 2^31-1 hypotheses in one batch");
+    if (n_problems == 0 || hyp_per_problem == 0)
+        return PH_OK;
+    if (!d_point_offsets || !d_subsets || !d_models || !d_counts)
+        return fail(PH_ERR_INVALID_ARG, "null pointer");
+    const double thr = reproj_err;
+    PH_HIP(ransac_hypotheses_launch(d_obj, d_img, 0, camera_of(K), d_subsets, d_point_offsets,
+                                    n_problems, hyp_per_problem, (float)(thr * thr), d_models,
+                                    d_counts, g_ctx.n_cus, pick_stream(stream)));
     return PH_OK;
 }
 
@@ -743,8 +770,8 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
     for (int base = 0; base < total && base < niters; base += chunk) {
         const int m = std::min(chunk, total - base);
         PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, cam,
-                                        (const int32_t *)g_ctx.pnp_sub.p + (size_t)base * 5, m,
-                                        thr2, (double *)g_ctx.pnp_models.p,
+                                        (const int32_t *)g_ctx.pnp_sub.p + (size_t)base * 5, nullptr,
+                                        1, m, thr2, (double *)g_ctx.pnp_models.p,
                                         (int32_t *)g_ctx.pnp_counts.p, g_ctx.n_cus, st));
         PH_HIP(hipMemcpyAsync(models.data(), g_ctx.pnp_models.p, (size_t)m * 6 * sizeof(double),
                               hipMemcpyDeviceToHost, st));

@@ -9,10 +9,13 @@ struct CameraK {
     double fx, fy, cx, cy;
 };
 
-// n_hyp hypotheses: EPnP on rows d_subsets[5h..5h+5) -> d_models[6h..] = rvec|tvec and the
-// inlier count over all n rows -> d_counts[h].  thr2 = (float)(reprojectionError^2).
+// n_problems x hyp_per_problem hypotheses: EPnP on rows d_subsets[5h..5h+5) of the
+// hypothesis' problem -> d_models[6h..] = rvec|tvec and the inlier count over that problem's
+// rows -> d_counts[h].  Problem p owns rows [d_offsets[p], d_offsets[p+1]); d_offsets ==
+// nullptr means one problem over rows 0..n.  thr2 = (float)(reprojectionError^2).
 hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int n, CameraK K,
-                                    const int32_t *d_subsets, int n_hyp, float thr2,
+                                    const int32_t *d_subsets, const int32_t *d_offsets,
+                                    int n_problems, int hyp_per_problem, float thr2,
                                     double *d_models, int32_t *d_counts, int n_cus,
                                     hipStream_t stream);
 

@@ -258,6 +258,140 @@ __device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep,
     }
 }
 
+// The 12 x 12 instance of jacobi_svd<ST, false> with row i held in registers
+// across the inner j loop (half the LDS traffic per rotation).  Same operations
+// in the same order, so the results are bit-identical to the generic routine.
+template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
+{
+    constexpr int N = 12;
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const double t = At[i * N + k];
+            sd += t * t;
+        }
+        W[i] = sd;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+        for (int i = 0; i < N - 1; i++) {
+            const LP<ST> Ai = At + i * N;
+            double ai[N];
+#pragma unroll
+            for (int k = 0; k < N; k++)
+                ai[k] = Ai[k];
+            double wi = W[i];
+            bool dirty = false;
+            for (int j = i + 1; j < N; j++) {
+                const LP<ST> Aj = At + j * N;
+                double aj[N];
+#pragma unroll
+                for (int k = 0; k < N; k++)
+                    aj[k] = Aj[k];
+                double a = wi, p = 0, b = W[j];
+#pragma unroll
+                for (int k = 0; k < N; k++)
+                    p += ai[k] * aj[k];
+                if (fabs(p) <= eps * sqrt(a * b))
+                    continue;
+                p *= 2;
+                const double beta = a - b, gamma = hypot_cr(p, beta);
+                double c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const double t0 = c * ai[k] + s * aj[k];
+                    const double t1 = -s * ai[k] + c * aj[k];
+                    ai[k] = t0;
+                    Aj[k] = t1;
+                    a += t0 * t0;
+                    b += t1 * t1;
+                }
+                wi = a;
+                W[j] = b;
+                changed = true;
+                dirty = true;
+            }
+            if (dirty) {
+#pragma unroll
+                for (int k = 0; k < N; k++)
+                    Ai[k] = ai[k];
+                W[i] = wi;
+            }
+        }
+        if (!changed)
+            break;
+    }
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const double t = At[i * N + k];
+            sd += t * t;
+        }
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < N - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < N; k++)
+            if (W[j] < W[k])
+                j = k;
+        if (i != j) {
+            double t = W[i];
+            W[i] = W[j];
+            W[j] = t;
+            for (int k = 0; k < N; k++) {
+                t = At[i * N + k];
+                At[i * N + k] = At[j * N + k];
+                At[j * N + k] = t;
+            }
+        }
+    }
+    Rng rng{0x12345678};
+    for (int i = 0; i < N; i++) {
+        double sd = W[i];
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const double val0 = 1. / N;
+            for (int k = 0; k < N; k++)
+                At[i * N + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+            for (int it = 0; it < 2; it++)
+                for (int j = 0; j < i; j++) {
+                    sd = 0;
+                    for (int k = 0; k < N; k++)
+                        sd += At[i * N + k] * At[j * N + k];
+                    double asum = 0;
+                    for (int k = 0; k < N; k++) {
+                        const double t = At[i * N + k] - sd * At[j * N + k];
+                        At[i * N + k] = t;
+                        asum += fabs(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+                    for (int k = 0; k < N; k++)
+                        At[i * N + k] *= asum;
+                }
+            sd = 0;
+            for (int k = 0; k < N; k++) {
+                const double t = At[i * N + k];
+                sd += t * t;
+            }
+            sd = sqrt(sd);
+        }
+        const double s = sd > minval ? 1 / sd : 0.;
+        for (int k = 0; k < N; k++)
+            At[i * N + k] *= s;
+    }
+}
+
 // A lane's LDS arrays (offsets in doubles; LDS_DOUBLES per hypothesis).
 constexpr int OFF_UT = 0;    // 12 x 12: MtM, then its left singular vectors (rows)
 constexpr int OFF_W = 144;   // 12
@@ -742,7 +876,7 @@ __device__ void epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3],
     accumulate_mtm(P, e, S);
     PNP_STAMP(3);
     // MtM is symmetric, so it is its own transposed copy; EPnP reads only U
-    jacobi_svd<ST, false>(S.ut, 12, S.w, S.w, 0, 12, 12);
+    jacobi_svd_12<ST>(S.ut, S.w);
     PNP_STAMP(4);
     compute_L_6x10(S.ut, S.l);
     PNP_STAMP(5);
@@ -886,11 +1020,16 @@ __device__ inline Points make_points(const float *obj, const float *img, const i
 // Solve kernel: lane l < HPW of workgroup b solves hypothesis h = b*HPW + l (EPnP
 // on rows subsets[5h .. 5h+5)) and writes its model (rvec, tvec) to models[6h..].
 // Dynamic LDS: HPW * LDS_DOUBLES doubles.
+// A batch holds n_problems independent problems of hyp_per_problem hypotheses
+// each; problem p owns the correspondence rows [offsets[p], offsets[p+1]) (offsets
+// == nullptr: one problem over all rows) and its subsets index rows of that range.
 template <int HPW>
 __global__ __launch_bounds__(64) void ransac_solve_kernel(const float *__restrict__ obj,
                                                           const float *__restrict__ img, CameraK K,
                                                           const int32_t *__restrict__ subsets,
-                                                          int n_hyp, double *__restrict__ models)
+                                                          const int32_t *__restrict__ offsets,
+                                                          int hyp_per_problem, int n_hyp,
+                                                          double *__restrict__ models)
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -898,7 +1037,8 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(const float *__restric
     if (lane >= HPW || h >= n_hyp)
         return;
     const EpnpLds<HPW> S(lds + lane);
-    const Points P = make_points(obj, img, subsets + (int64_t)h * 5, 5, K);
+    const int64_t row0 = offsets ? offsets[h / hyp_per_problem] : 0;
+    const Points P = make_points(obj + 3 * row0, img + 2 * row0, subsets + (int64_t)h * 5, 5, K);
     double R[3][3], t[3], r[3];
     epnp_pose(P, S, R, t);
     rodrigues_mat_to_vec(S, R, r);
@@ -914,13 +1054,21 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restri
                                                            const float *__restrict__ img, int n,
                                                            CameraK K,
                                                            const double *__restrict__ models,
-                                                           int n_hyp, float thr2,
-                                                           int32_t *__restrict__ counts)
+                                                           const int32_t *__restrict__ offsets,
+                                                           int hyp_per_problem, int n_hyp,
+                                                           float thr2, int32_t *__restrict__ counts)
 {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= n_hyp)
         return;
+    if (offsets) {
+        const int p = h / hyp_per_problem;
+        const int64_t row0 = offsets[p];
+        n = offsets[p + 1] - offsets[p];
+        obj += 3 * row0;
+        img += 2 * row0;
+    }
     const double *m = models + (int64_t)h * 6;
     const double r[3] = {m[0], m[1], m[2]}, tv[3] = {m[3], m[4], m[5]};
     double Rm[9];
@@ -970,7 +1118,8 @@ __global__ __launch_bounds__(64) void epnp_solve_kernel(const float *__restrict_
 
 template <int HPW>
 static hipError_t launch_solve(const float *d_obj, const float *d_img, CameraK K,
-                               const int32_t *d_subsets, int n_hyp, double *d_models,
+                               const int32_t *d_subsets, const int32_t *d_offsets,
+                               int hyp_per_problem, int n_hyp, double *d_models,
                                hipStream_t stream)
 {
     const size_t lds_bytes = (size_t)HPW * LDS_DOUBLES * sizeof(double);
@@ -984,29 +1133,38 @@ static hipError_t launch_solve(const float *d_obj, const float *d_img, CameraK K
         configured = true;
     }
     ransac_solve_kernel<HPW><<<(n_hyp + HPW - 1) / HPW, 64, lds_bytes, stream>>>(
-        d_obj, d_img, K, d_subsets, n_hyp, d_models);
+        d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp, d_models);
     return hipGetLastError();
 }
 
 hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int n, CameraK K,
-                                    const int32_t *d_subsets, int n_hyp, float thr2,
+                                    const int32_t *d_subsets, const int32_t *d_offsets,
+                                    int n_problems, int hyp_per_problem, float thr2,
                                     double *d_models, int32_t *d_counts, int n_cus,
                                     hipStream_t stream)
 {
-    if (n_hyp <= 0)
+    const int64_t total = (int64_t)n_problems * hyp_per_problem;
+    if (total <= 0)
         return hipSuccess;
+    if (total > 0x7FFFFFFF)
+        return hipErrorInvalidValue;
+    const int n_hyp = (int)total;
     // Hypotheses per wave: few hypotheses -> 16 per wave (4 waves per CU, one
     // per SIMD, as many CUs as possible); many -> 64 per wave (all lanes busy).
     hipError_t e;
     if (n_hyp <= n_cus * 4 * 16)
-        e = launch_solve<16>(d_obj, d_img, K, d_subsets, n_hyp, d_models, stream);
+        e = launch_solve<16>(d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp,
+                             d_models, stream);
     else if (n_hyp <= n_cus * 2 * 32)
-        e = launch_solve<32>(d_obj, d_img, K, d_subsets, n_hyp, d_models, stream);
+        e = launch_solve<32>(d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp,
+                             d_models, stream);
     else
-        e = launch_solve<64>(d_obj, d_img, K, d_subsets, n_hyp, d_models, stream);
+        e = launch_solve<64>(d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp,
+                             d_models, stream);
     if (e != hipSuccess)
         return e;
-    ransac_score_kernel<<<(n_hyp + 3) / 4, 256, 0, stream>>>(d_obj, d_img, n, K, d_models, n_hyp,
+    ransac_score_kernel<<<(n_hyp + 3) / 4, 256, 0, stream>>>(d_obj, d_img, n, K, d_models,
+                                                             d_offsets, hyp_per_problem, n_hyp,
                                                              thr2, d_counts);
     return hipGetLastError();
 }

@@ -144,3 +144,36 @@ def test_invalid_arguments(posehip):
         pa.solvePnPRansac(obj, img, datagen.CAMERA_K, None, confidence=1.0)
     with pytest.raises(ValueError):
         pa.solvePnPRansac(obj, img, datagen.CAMERA_K, np.array([0.1, 0, 0, 0]))
+
+
+def test_batched_hypotheses_match_oracle(posehip):
+    """Three problems of different sizes in one launch: every problem's models and
+    counts equal the oracle's for that problem alone."""
+    import torch
+    dev = torch.device("cuda", 0)
+    sizes, H = [700, 2000, 333], 96
+    objs, imgs, subs = [], [], []
+    for p, n in enumerate(sizes):
+        obj, img, R, t, _ = datagen.pnp_scene(n=n, seed=20 + p, angle_deg=20.0 + 15 * p)
+        objs.append(obj)
+        imgs.append(img)
+        subs.append(orc.ransac_subsets(n, H, rng_state=1234 + p))
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    d_obj = torch.from_numpy(np.concatenate(objs)).to(dev)
+    d_img = torch.from_numpy(np.concatenate(imgs)).to(dev)
+    d_sub = torch.from_numpy(np.concatenate(subs)).to(dev)
+    d_off = torch.from_numpy(offsets).to(dev)
+    d_models = torch.zeros((len(sizes) * H, 6), dtype=torch.float64, device=dev)
+    d_counts = torch.zeros(len(sizes) * H, dtype=torch.int32, device=dev)
+    Kc = np.ascontiguousarray(datagen.CAMERA_K, np.float64).reshape(9)
+    torch.cuda.synchronize()
+    posehip.check(posehip.load().ph_ransac_epnp_hypotheses_batched_dev(
+        d_obj.data_ptr(), d_img.data_ptr(), d_off.data_ptr(), len(sizes),
+        Kc.ctypes.data_as(C.POINTER(C.c_double)), d_sub.data_ptr(), H, 8.0, d_models.data_ptr(),
+        d_counts.data_ptr(), None))
+    posehip.check(posehip.load().ph_stream_synchronize(None))
+    models, counts = d_models.cpu().numpy(), d_counts.cpu().numpy()
+    for p in range(len(sizes)):
+        rm, rc = orc.pnp_hypotheses(objs[p], imgs[p], datagen.CAMERA_K, subs[p])
+        assert np.array_equal(counts[p * H:(p + 1) * H], rc)
+        assert np.abs(models[p * H:(p + 1) * H] - rm).max() < 1e-12
