@@ -39,7 +39,16 @@ def parse():
     ap.add_argument("--ransac-problems", type=int, default=16,
                     help="independent RANSAC problems per step per GPU (one call each)")
     ap.add_argument("--ransac-steps", type=int, default=10)
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL, the default) or gloo (rehearsing N ranks on fewer GPUs)")
     return ap.parse_args()
+
+
+def all_reduce_max(value, torch, dist, dev, backend):
+    """MAX over ranks of a host float (device tensor under RCCL, host tensor under gloo)."""
+    t = torch.tensor([value], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
@@ -98,9 +107,7 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
         dist.barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        tm = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        el = float(tm.item())
+        el = all_reduce_max(el, torch, dist, dev, args.dist_backend)
     res = {
         "value": float(H) * P * world * args.ransac_steps / el,
         "unit": "hypotheses/s",
@@ -150,13 +157,18 @@ def main():
         print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; under --dist-backend gloo several ranks may share a GPU (rehearsal)
+    dev_index = local_rank if args.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from poseestimation_amd import _lib
-    _lib.init(local_rank)
+    _lib.init(dev_index)
     lib = _lib.load()
 
     nq, nt, F = args.nq, args.nt, args.frames_per_step
@@ -205,9 +217,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = all_reduce_max(elapsed, torch, dist, dev, args.dist_backend)
 
     evals_per_step_all = float(nq) * nt * F * world
     value = evals_per_step_all * args.steps / elapsed

@@ -300,3 +300,39 @@ def test_crosscheck_dev(posehip):
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
     got = [(int(i), int(idx[i]), 0, float(dist[i])) for i in range(3000) if idx[i] >= 0]
     assert got == orc.match(q, t, cross_check=True)
+
+
+def test_train_set_beyond_one_key_range(posehip):
+    """More train rows than one 22-bit split index holds (4 194 304): the split cap and
+    the cross-split tie-break (equal rows planted on both sides of the boundary)."""
+    nt = (1 << 22) + 4099
+    t = datagen.random_descriptors(nt, 81)
+    q = datagen.random_descriptors(130, 82)
+    # identical copies of query rows far apart: lowest index must win, second = next copy
+    t[(1 << 22) + 7] = q[0]
+    t[123] = q[0]
+    t[(1 << 22) - 1] = q[1]
+    t[(1 << 22)] = q[1]
+    t[nt - 1] = q[2]
+    idx, dist, _ = gpu_knn_dev(posehip, _dev(q), _dev(t), 2)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    ridx, rdist = orc.knn(q, t, 2, threads=8)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    assert idx[0].tolist() == [123, (1 << 22) + 7] and dist[0].tolist() == [0, 0]
+    assert idx[1].tolist() == [(1 << 22) - 1, 1 << 22]
+    assert idx[2, 0] == nt - 1 and dist[2, 0] == 0
+
+
+def test_index_base_and_overflow_guard(posehip):
+    q = datagen.random_descriptors(70, 91)
+    t = datagen.random_descriptors(300, 92)
+    idx, dist, _ = gpu_knn_dev(posehip, _dev(q), _dev(t), 2, base=1_000_000)
+    ridx, rdist = orc.knn(q, t, 2)
+    assert np.array_equal(idx.cpu().numpy(), ridx + 1_000_000)
+    assert np.array_equal(dist.cpu().numpy(), rdist)
+    import torch
+    out = torch.empty((70, 2), dtype=torch.int32, device="cuda:0")
+    st = posehip.load().ph_knn_hamming256_dev(_dev(q).data_ptr(), 70, _dev(t).data_ptr(), 300, 2,
+                                              2**31 - 100, out.data_ptr(), out.data_ptr(), None,
+                                              0.0, None)
+    assert st == 5  # PH_ERR_TOO_LARGE: base + nt would not fit an int32 index
