@@ -25,6 +25,7 @@ struct KnnPlan {
 
 KnnPlan knn_plan(int64_t nq, int64_t nt, int n_cus);
 KnnPlan knn_plan_custom(int64_t nq, int64_t nt, int waves, bool lazy, int64_t max_blocks);
+KnnPlan knn_plan_splits(int64_t nq, int64_t nt, int waves, bool lazy, int64_t splits);
 
 hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const void *d_train,
                       int64_t nt, int k, int32_t index_base, uint32_t *d_part, int32_t *d_out_idx,

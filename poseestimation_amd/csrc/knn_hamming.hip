@@ -349,15 +349,13 @@ __global__ __launch_bounds__(256) void cc_finalize_kernel(
 
 // ---- launchers ---------------------------------------------------------------
 
-KnnPlan knn_plan_custom(int64_t nq, int64_t nt, int waves, bool lazy, int64_t max_blocks)
+KnnPlan knn_plan_splits(int64_t nq, int64_t nt, int waves, bool lazy, int64_t splits)
 {
     KnnPlan p;
     p.waves = waves;
     p.lazy = lazy;
     p.q_blocks = (nq + 63) / 64;
-    // As many train splits as keep the grid within max_blocks (the workgroups
-    // that can be resident at once), each wave streaming >= 64 rows.
-    int64_t splits = max_blocks / p.q_blocks;
+    // every wave streams >= 64 rows; the grid's y extent is 16 bits
     const int64_t max_splits = (nt + 64 * waves - 1) / (64 * waves);
     if (splits > max_splits)
         splits = max_splits;
@@ -378,16 +376,34 @@ KnnPlan knn_plan_custom(int64_t nq, int64_t nt, int waves, bool lazy, int64_t ma
     return p;
 }
 
+KnnPlan knn_plan_custom(int64_t nq, int64_t nt, int waves, bool lazy, int64_t max_blocks)
+{
+    const int64_t q_blocks = (nq + 63) / 64;
+    return knn_plan_splits(nq, nt, waves, lazy, max_blocks / q_blocks);
+}
+
+// Launch plan (measured on MI355X from 500 x 500 to 1M x 50k, tools/knn_sweep):
+//  * workgroups of 4 waves (8 when there are very few query blocks);
+//  * enough train splits to fill the chip: at least the split count that makes
+//    8 workgroups per CU resident, and beyond that about 1024 train rows per
+//    workgroup, because many short workgroups balance the 256 CUs better than a
+//    few long ones -- up to about 48 workgroups per CU;
+//  * with so many query blocks that one split already gives every CU dozens of
+//    workgroups, no split at all: long streams let the lazy key update skip
+//    almost every update.
 KnnPlan knn_plan(int64_t nq, int64_t nt, int n_cus)
 {
-    // 4-wave workgroups, 8 resident per CU (8 waves per SIMD).  When one split
-    // already gives every wave thousands of rows, 8-wave workgroups halve the
-    // rows per wave for the same residency; the lazy key update pays once a
-    // wave streams about a thousand rows.
-    KnnPlan p = knn_plan_custom(nq, nt, 4, false, (int64_t)n_cus * 8);
-    if (p.rows_per_wave >= 8192)
-        p = knn_plan_custom(nq, nt, 8, false, (int64_t)n_cus * 4);
-    p.lazy = p.rows_per_wave >= 1024;
+    const int64_t q_blocks = (nq + 63) / 64;
+    const int waves = q_blocks * 4 <= n_cus ? 8 : 4;
+    const int64_t resident = (int64_t)n_cus * 32 / waves; // workgroups at 8 waves per SIMD
+    const int64_t fill = resident / q_blocks;             // floor: keep them all resident
+    const int64_t by_rows = nt / (256 * (int64_t)waves);
+    const int64_t cap = (48 * (int64_t)n_cus + q_blocks - 1) / q_blocks;
+    int64_t splits = by_rows < cap ? by_rows : cap;
+    if (splits < fill)
+        splits = fill;
+    KnnPlan p = knn_plan_splits(nq, nt, waves, false, splits);
+    p.lazy = p.rows_per_wave >= 3072;
     return p;
 }
 

@@ -39,9 +39,9 @@ int main(int argc, char **argv)
     CK(hipMemcpy(r_d.data(), dd0, nq * 8, hipMemcpyDeviceToHost));
     struct V { int waves; bool lazy; int per_simd; };
     std::vector<V> vs;
-    for (int waves : {1, 2, 4, 8, 16})
+    for (int waves : {2, 4, 8})
         for (int lazy : {0, 1})
-            for (int waves_per_simd : {2, 4, 6, 8})
+            for (int waves_per_simd : {4, 8, 12, 16, 24, 32, 48})
                 vs.push_back({waves, lazy != 0, waves_per_simd});
     for (auto v : vs) {
         const long max_blocks = (long)256 * 4 * v.per_simd / v.waves; // resident workgroups

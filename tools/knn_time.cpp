@@ -15,7 +15,7 @@ int main(int argc, char **argv)
 {
     PH(ph_init(0));
     struct Sz { long nq, nt; int reps; };
-    std::vector<Sz> sizes = {{500, 500, 50}, {10000, 10000, 50}, {100000, 50000, 10}, {2000 * 256, 50000, 3}};
+    std::vector<Sz> sizes = {{500, 500, 50}, {2000, 50000, 50}, {4096, 50000, 30}, {10000, 10000, 50}, {30000, 10000, 30}, {50000, 20000, 20}, {100000, 10000, 20}, {100000, 50000, 10}, {262144, 16384, 10}, {1000000, 50000, 3}};
     if (argc == 3) sizes = {{atol(argv[1]), atol(argv[2]), 10}};
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
