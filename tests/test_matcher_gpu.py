@@ -336,3 +336,64 @@ def test_index_base_and_overflow_guard(posehip):
                                               2**31 - 100, out.data_ptr(), out.data_ptr(), None,
                                               0.0, None)
     assert st == 5  # PH_ERR_TOO_LARGE: base + nt would not fit an int32 index
+
+
+def test_long_stream_k1_and_lazy_path(posehip):
+    """k = 1 on a shape that takes the no-split, lazy-update plan (1.1M queries): sampled
+    rows against the oracle; planted exact copies must be found at their lowest index."""
+    nq, nt = 1_100_000, 9000
+    q = datagen.random_descriptors(nq, 17)
+    t = datagen.random_descriptors(nt, 18)
+    t[5000] = q[10]
+    t[7000] = q[10]
+    t[8999] = q[nq - 1]
+    for k in (1, 2):
+        idx, dist, _ = gpu_knn_dev(posehip, _dev(q), _dev(t), k)
+        idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+        rows = np.random.default_rng(k).choice(nq, 256, replace=False)
+        rows[:2] = [10, nq - 1]
+        ridx, rdist = orc.knn(q[rows], t, k, threads=8)
+        assert np.array_equal(idx[rows], ridx) and np.array_equal(dist[rows], rdist)
+        assert idx[10, 0] == 5000 and dist[10, 0] == 0 and idx[nq - 1, 0] == 8999
+        if k == 2:
+            assert idx[10, 1] == 7000 and dist[10, 1] == 0
+
+
+def test_calls_from_two_threads(posehip):
+    """The reference calls the matcher from a std::async worker (src/cereal_box.cpp:280):
+    entry points must work from any thread and serialise internally."""
+    import threading
+    q = datagen.random_descriptors(600, 33)
+    t = datagen.random_descriptors(900, 34)
+    want = orc.knn(q, t, 2)
+    errs = []
+
+    def work():
+        try:
+            for _ in range(20):
+                idx, dist = gpu_knn(posehip, q, t, 2)
+                assert np.array_equal(idx, want[0]) and np.array_equal(dist, want[1])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work) for _ in range(3)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+
+
+def test_shutdown_and_reinit(posehip):
+    lib = posehip.load()
+    q = datagen.random_descriptors(100, 35)
+    lib.ph_shutdown()
+    assert lib.ph_device() == -1
+    u8, i32 = C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    out = np.zeros((100, 1), np.int32)
+    st = lib.ph_knn_hamming256(q.ctypes.data_as(u8), 100, 32, q.ctypes.data_as(u8), 100, 32, 1,
+                               out.ctypes.data_as(i32), out.ctypes.data_as(i32))
+    assert st == 4  # PH_ERR_NOT_INITIALIZED: no silent fallback
+    posehip.init(0)
+    idx, dist = gpu_knn(posehip, q, q, 1)
+    assert (idx[:, 0] == np.arange(100)).all() and (dist == 0).all()
