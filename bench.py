@@ -7,7 +7,7 @@ Workload at every N (weak scaling): per rank, a step is one pass over a batch of
 same 10k-row train set, inputs resident in HBM.  Frames are independent, so
 ranks share nothing and no collective is on the data path.
 
-Prints one JSON line on rank 0 (see README/DESIGN for the fields).
+Prints one JSON line on rank 0.
 """
 import argparse
 import ctypes as C

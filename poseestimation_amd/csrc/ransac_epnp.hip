@@ -461,6 +461,10 @@ struct Points {
     const float *img;
     const int32_t *idx;
     int n;
+    // Sums over the points run i = first, first + step, ...: (0, 1) when a lane
+    // owns its problem, (lane, 64) when the 64 lanes of a wave share one problem
+    // and combine their partial sums with wave_sum().
+    int first, step;
     double fu, fv, uc, vc, ifx, ify;
     __device__ void world(int i, double *pw) const
     {
@@ -479,6 +483,15 @@ struct Points {
         v = yn * fv + vc;
     }
 };
+
+// Sum of x over the 64 lanes (fixed butterfly order; every lane gets the same value).
+__device__ inline double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        x += __shfl_xor(x, off, 64);
+    return x;
+}
 
 struct EpnpState {
     double cws[4][3];
@@ -509,21 +522,28 @@ __device__ void choose_control_points(const Points &P, EpnpState &e, const EpnpL
 {
     const int n = P.n;
     e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
-    for (int i = 0; i < n; i++) {
+    for (int i = P.first; i < n; i += P.step) {
         double pw[3];
         P.world(i, pw);
         for (int j = 0; j < 3; j++)
             e.cws[0][j] += pw[j];
     }
+    if (P.step > 1)
+        for (int j = 0; j < 3; j++)
+            e.cws[0][j] = wave_sum(e.cws[0][j]);
     for (int j = 0; j < 3; j++)
         e.cws[0][j] /= n;
     double m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
-    for (int i = 0; i < n; i++) {
+    for (int i = P.first; i < n; i += P.step) {
         double pw[3];
         P.world(i, pw);
         const double d0 = pw[0] - e.cws[0][0], d1 = pw[1] - e.cws[0][1], d2 = pw[2] - e.cws[0][2];
         m00 += d0 * d0; m01 += d0 * d1; m02 += d0 * d2;
         m11 += d1 * d1; m12 += d1 * d2; m22 += d2 * d2;
+    }
+    if (P.step > 1) {
+        m00 = wave_sum(m00); m01 = wave_sum(m01); m02 = wave_sum(m02);
+        m11 = wave_sum(m11); m12 = wave_sum(m12); m22 = wave_sum(m22);
     }
     // symmetric, so the transposed copy the SVD works on equals the matrix
     S.sa[0] = m00; S.sa[1] = m01; S.sa[2] = m02;
@@ -572,13 +592,16 @@ template <int ST> __device__ void compute_basis_inverse(EpnpState &e, const Epnp
 template <int ST>
 __device__ void accumulate_mtm(const Points &P, const EpnpState &e, const EpnpLds<ST> &S)
 {
-    for (int i = 0; i < 144; i++)
-        S.ut[i] = 0;
-    for (int i = 0; i < P.n; i++) {
+    double acc[78]; // upper triangle, row-major
+#pragma unroll
+    for (int i = 0; i < 78; i++)
+        acc[i] = 0;
+    for (int i = P.first; i < P.n; i += P.step) {
         double pw[3], as[4], u, v, m1[12], m2[12];
         P.world(i, pw);
         P.pixel(i, u, v);
         alphas_of(e, pw, as);
+#pragma unroll
         for (int k = 0; k < 4; k++) {
             m1[3 * k] = as[k] * P.fu;
             m1[3 * k + 1] = 0.0;
@@ -587,19 +610,26 @@ __device__ void accumulate_mtm(const Points &P, const EpnpState &e, const EpnpLd
             m2[3 * k + 1] = as[k] * P.fv;
             m2[3 * k + 2] = as[k] * (P.vc - v);
         }
+        int o = 0;
+#pragma unroll
         for (int a = 0; a < 12; a++)
-            for (int b = a; b < 12; b++) {
-                double s = S.ut[a * 12 + b];
+#pragma unroll
+            for (int b = a; b < 12; b++, o++) {
                 if (a % 3 != 1 && b % 3 != 1)
-                    s += m1[a] * m1[b];
+                    acc[o] += m1[a] * m1[b];
                 if (a % 3 != 0 && b % 3 != 0)
-                    s += m2[a] * m2[b];
-                S.ut[a * 12 + b] = s;
+                    acc[o] += m2[a] * m2[b];
             }
     }
+    int o = 0;
+#pragma unroll
     for (int a = 0; a < 12; a++)
-        for (int b = a + 1; b < 12; b++)
-            S.ut[b * 12 + a] = S.ut[a * 12 + b];
+#pragma unroll
+        for (int b = a; b < 12; b++, o++) {
+            const double v = P.step > 1 ? wave_sum(acc[o]) : acc[o];
+            S.ut[a * 12 + b] = v;
+            S.ut[b * 12 + a] = v;
+        }
 }
 
 template <int ST> __device__ void compute_L_6x10(LP<ST> ut, LP<ST> l)
@@ -803,7 +833,7 @@ __device__ double compute_R_and_t(const Points &P, EpnpState &e, const EpnpLds<S
         e.flip = pc[2] < 0.0;
     }
     double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
-    for (int i = 0; i < n; i++) {
+    for (int i = P.first; i < n; i += P.step) {
         double pw[3], a[4], pc[3];
         P.world(i, pw);
         alphas_of(e, pw, a);
@@ -813,12 +843,17 @@ __device__ double compute_R_and_t(const Points &P, EpnpState &e, const EpnpLds<S
             pw0[j] += pw[j];
         }
     }
+    if (P.step > 1)
+        for (int j = 0; j < 3; j++) {
+            pc0[j] = wave_sum(pc0[j]);
+            pw0[j] = wave_sum(pw0[j]);
+        }
     for (int j = 0; j < 3; j++) {
         pc0[j] /= n;
         pw0[j] /= n;
     }
     double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < n; i++) {
+    for (int i = P.first; i < n; i += P.step) {
         double pw[3], a[4], pc[3];
         P.world(i, pw);
         alphas_of(e, pw, a);
@@ -829,6 +864,9 @@ __device__ double compute_R_and_t(const Points &P, EpnpState &e, const EpnpLds<S
             abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
         }
     }
+    if (P.step > 1)
+        for (int j = 0; j < 9; j++)
+            abt[j] = wave_sum(abt[j]);
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
             S.sa[i * 3 + j] = abt[j * 3 + i];
@@ -849,7 +887,7 @@ __device__ double compute_R_and_t(const Points &P, EpnpState &e, const EpnpLds<S
     t[1] = pc0[1] - dot3(R[1], pw0);
     t[2] = pc0[2] - dot3(R[2], pw0);
     double sum2 = 0.0;
-    for (int i = 0; i < n; i++) {
+    for (int i = P.first; i < n; i += P.step) {
         double pw[3], u, v;
         P.world(i, pw);
         P.pixel(i, u, v);
@@ -860,6 +898,8 @@ __device__ double compute_R_and_t(const Points &P, EpnpState &e, const EpnpLds<S
         const double ve = P.vc + P.fv * Yc * inv_Zc;
         sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
     }
+    if (P.step > 1)
+        sum2 = wave_sum(sum2);
     return sum2 / n;
 }
 
@@ -1006,6 +1046,8 @@ __device__ inline Points make_points(const float *obj, const float *img, const i
     P.img = img;
     P.idx = idx;
     P.n = n;
+    P.first = 0;
+    P.step = 1;
     P.fu = K.fx;
     P.fv = K.fy;
     P.uc = K.cx;
@@ -1099,21 +1141,32 @@ __global__ __launch_bounds__(256) void inlier_mask_kernel(const float *__restric
 }
 
 // solvePnP(SOLVEPNP_EPNP) on rows idx[0..n) (idx may be null): model[6] = rvec|tvec.
+// One wave, one problem: every lane runs the whole solve on its own LDS copy
+// (the 64-hypothesis layout), but the sums over the n points are split over the
+// lanes and combined with wave_sum(), so a refit on thousands of inliers costs
+// little more than a 5-point solve.  (The split changes the order of those sums:
+// the result differs from a sequential statement by rounding, ~1e-13 relative.)
+// n < 64 runs the sequential order on every lane instead.
 __global__ __launch_bounds__(64) void epnp_solve_kernel(const float *__restrict__ obj,
                                                         const float *__restrict__ img,
                                                         const int32_t *__restrict__ idx, int n,
                                                         CameraK K, double *__restrict__ model)
 {
-    __shared__ double lds1[LDS_DOUBLES];
-    if (threadIdx.x != 0)
-        return;
-    const EpnpLds<1> S(lds1);
-    const Points P = make_points(obj, img, idx, n, K);
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const EpnpLds<64> S(lds + lane);
+    Points P = make_points(obj, img, idx, n, K);
+    if (n >= 64) {
+        P.first = lane;
+        P.step = 64;
+    }
     double R[3][3], t[3], r[3];
     epnp_pose(P, S, R, t);
     rodrigues_mat_to_vec(S, R, r);
-    model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
-    model[3] = t[0]; model[4] = t[1]; model[5] = t[2];
+    if (lane == 0) {
+        model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
+        model[3] = t[0]; model[4] = t[1]; model[5] = t[2];
+    }
 }
 
 template <int HPW>
@@ -1183,7 +1236,17 @@ hipError_t inlier_mask_launch(const float *d_obj, const float *d_img, int n, Cam
 hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,
                              CameraK K, double *d_model, hipStream_t stream)
 {
-    epnp_solve_kernel<<<1, 64, 0, stream>>>(d_obj, d_img, d_idx, n, K, d_model);
+    const size_t lds_bytes = (size_t)64 * LDS_DOUBLES * sizeof(double);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)epnp_solve_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess)
+            return e;
+        configured = true;
+    }
+    epnp_solve_kernel<<<1, 64, lds_bytes, stream>>>(d_obj, d_img, d_idx, n, K, d_model);
     return hipGetLastError();
 }
 
