@@ -14,7 +14,7 @@
 // ONE HYPOTHESIS PER LANE: every instruction of that chain serves up to 64
 // hypotheses.  Each lane keeps its small matrices (12 x 12 null-space problem,
 // 6 x 10 system, ...) in LDS, interleaved over the lanes (element e of lane l at
-// word e*HPW + l, so a wave access is conflict-free), 2472 bytes per hypothesis.
+// word e*HPW + l, so a wave access is conflict-free), 1632 bytes per hypothesis.
 // Every operation is in the order of a plain sequential statement of the
 // algorithm (built with -ffp-contract=off) so that poses agree with a CPU
 // statement to the last bits.  Per-point quantities (barycentric coordinates,
@@ -392,15 +392,22 @@ template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
     }
 }
 
-// A lane's LDS arrays (offsets in doubles; LDS_DOUBLES per hypothesis).
-constexpr int OFF_UT = 0;    // 12 x 12: MtM, then its left singular vectors (rows)
+// A lane's LDS arrays (offsets in doubles; LDS_DOUBLES per hypothesis).  Lifetimes
+// overlap so that the peak is the 12 x 12 matrix plus the small-SVD scratch:
+//   ut  12 x 12: MtM, then its left singular vectors (rows); only rows 8..11
+//       (elements 96..143) are read after the decomposition, so
+//   l   (6 x 10) and ga (6 x 4 Gauss-Newton matrix) live in ut[0..84) from then on;
+//   sa/sv/sw  scratch of the small SVDs (At up to 5 x 6, Vt up to 5 x 5, W);
+//   w   the 12 row norms of the big decomposition, which shares sa (no small SVD
+//       runs meanwhile).
+constexpr int OFF_UT = 0;
+constexpr int OFF_L = 0;
+constexpr int OFF_GA = 60;
+constexpr int OFF_SA = 144;  // 30
 constexpr int OFF_W = 144;   // 12
-constexpr int OFF_SA = 156;  // small SVDs: At (up to 5 x 6)
-constexpr int OFF_SV = 192;  // small SVDs: Vt (up to 5 x 5)
-constexpr int OFF_SW = 217;  // small SVDs: W
-constexpr int OFF_L = 225;   // L_6x10
-constexpr int OFF_GA = 285;  // Gauss-Newton A (6 x 4)
-constexpr int LDS_DOUBLES = 309;
+constexpr int OFF_SV = 174;  // 25
+constexpr int OFF_SW = 199;  // 5
+constexpr int LDS_DOUBLES = 204; // 32 hypotheses = 51 KiB: three workgroups per CU
 
 template <int ST> struct EpnpLds {
     LP<ST> ut, w, sa, sv, sw, l, ga;
@@ -1202,17 +1209,16 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     if (total > 0x7FFFFFFF)
         return hipErrorInvalidValue;
     const int n_hyp = (int)total;
-    // Hypotheses per wave: few hypotheses -> 16 per wave (4 waves per CU, one
-    // per SIMD, as many CUs as possible); many -> 64 per wave (all lanes busy).
+    // Hypotheses per wave: the solve is latency-bound and LDS capacity (1632 B per
+    // hypothesis -> 96 per CU) sets how many are in flight, so few hypotheses go
+    // 16 to a wave (as many CUs and SIMDs as possible) and many go 32 to a wave
+    // (3 workgroups per CU).
     hipError_t e;
     if (n_hyp <= n_cus * 4 * 16)
         e = launch_solve<16>(d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp,
                              d_models, stream);
-    else if (n_hyp <= n_cus * 2 * 32)
-        e = launch_solve<32>(d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp,
-                             d_models, stream);
     else
-        e = launch_solve<64>(d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp,
+        e = launch_solve<32>(d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp,
                              d_models, stream);
     if (e != hipSuccess)
         return e;

@@ -34,6 +34,19 @@ int main(int argc, char **argv)
     CK(hipMemcpy(d_sub, sub.data(), sub.size() * 4, hipMemcpyHostToDevice));
     CameraK K{f, f, 400, 300};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (argc > 2) { // force hypotheses per workgroup: solve kernel only
+        const int hpw = atoi(argv[2]);
+        for (int r = 0; r < 3; r++) {
+            CK(hipEventRecord(e0));
+            if (hpw == 16) CK(launch_solve<16>(d_obj, d_img, K, d_sub, nullptr, H, H, d_models, 0));
+            else if (hpw == 32) CK(launch_solve<32>(d_obj, d_img, K, d_sub, nullptr, H, H, d_models, 0));
+            else CK(launch_solve<64>(d_obj, d_img, K, d_sub, nullptr, H, H, d_models, 0));
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("H=%d HPW=%d solve only: %.3f ms -> %.3g hyps/s\n", H, hpw, ms, H / (ms * 1e-3));
+        }
+        return 0;
+    }
     for (int r = 0; r < 3; r++) {
         CK(hipEventRecord(e0));
         CK(ransac_hypotheses_launch(d_obj, d_img, n, K, d_sub, nullptr, 1, H, 64.f, d_models, d_counts, 256, 0));
