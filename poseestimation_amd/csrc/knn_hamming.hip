@@ -11,8 +11,8 @@
 // instruction at all.  Per (query, train) pair the VALU executes
 //     8 x v_xor_b32 + 8 x v_bcnt_u32_b32 (accumulating)        = 16 ops
 //   + 1 x v_lshl_add_u32 (key = dist << 22 | local train index)
-//   + 1 x v_min_u32 + 1 x v_med3_u32 (running best / second best) =  3 ops
-// (the median-of-three is dropped for k = 1)
+//   + 1.25 ops for the running best / second best: four keys are folded with
+//     2 x v_min3_u32 + 2 x v_med3_u32 + 1 x v_min3_u32 (0.5 ops for k = 1)
 // Keys order by (distance, train index), so min / median-of-three reproduce
 // the strict-'<' insertion rule exactly.
 //
@@ -78,12 +78,38 @@ __device__ __forceinline__ uint32_t make_key(uint32_t d, uint32_t j)
     return r;
 }
 
+__device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // K == 2: running best and second best; K == 1: best only (one VALU op less).
 template <int K> __device__ __forceinline__ void top2_update(uint32_t &m1, uint32_t &m2, uint32_t key)
 {
     if constexpr (K == 2)
         m2 = med3_u32(m1, m2, key);
     m1 = min(m1, key);
+}
+
+// Four keys at once.  With m1 <= m2 and all keys distinct:
+//   best of {m1, k0, k1}        = min3, its runner-up = med3 (a candidate for second);
+//   best of {that, k2, k3}      = min3, its runner-up = med3 (another candidate);
+//   second best overall         = min3(m2, candidate, candidate).
+// 5 VALU ops for 4 keys (K == 2) or 2 ops (K == 1) instead of 8 / 4.
+template <int K>
+__device__ __forceinline__ void top2_update4(uint32_t &m1, uint32_t &m2, uint32_t k0, uint32_t k1,
+                                             uint32_t k2, uint32_t k3)
+{
+    const uint32_t a1 = min3_u32(m1, k0, k1);
+    const uint32_t a2 = min3_u32(a1, k2, k3);
+    if constexpr (K == 2) {
+        const uint32_t b1 = med3_u32(m1, k0, k1);
+        const uint32_t b2 = med3_u32(a1, k2, k3);
+        m2 = min3_u32(m2, b1, b2);
+    }
+    m1 = a2;
 }
 
 static constexpr int UNROLL = 4; // train rows per SGPR group (2 x s_load_dwordx16)
@@ -99,7 +125,7 @@ __device__ __forceinline__ void load_group(RowGroup &g, const Row *__restrict__ 
         g.r[u] = rows[u];
 }
 
-// Eager form: every pair updates the running keys (19 VALU ops per pair).
+// Eager form: every pair updates the running keys (18.25 VALU ops per pair).
 // Lazy form: the keys are touched only when some lane of the wave holds a
 // distance strictly below its current second-best distance (a later train row
 // with an equal distance can never enter, by the strict '<' rule), which costs
@@ -109,10 +135,13 @@ template <bool LAZY, int K>
 __device__ __forceinline__ void eval_group(const RowGroup &g, const uint32_t (&q)[8], uint32_t &m1,
                                            uint32_t &m2, uint32_t &thr, uint32_t j)
 {
+    static_assert(UNROLL == 4, "top2_update4 folds four keys");
     if constexpr (!LAZY) {
+        uint32_t key[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++)
-            top2_update<K>(m1, m2, make_key(hamming256(q, g.r[u]), j + u));
+            key[u] = make_key(hamming256(q, g.r[u]), j + u);
+        top2_update4<K>(m1, m2, key[0], key[1], key[2], key[3]);
     } else {
         uint32_t d[UNROLL];
 #pragma unroll
@@ -123,9 +152,8 @@ __device__ __forceinline__ void eval_group(const RowGroup &g, const uint32_t (&q
         for (int u = 1; u < UNROLL; u++)
             dmin = min(dmin, d[u]);
         if (__builtin_amdgcn_ballot_w64(dmin < thr) != 0) {
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++)
-                top2_update<K>(m1, m2, make_key(d[u], j + u));
+            top2_update4<K>(m1, m2, make_key(d[0], j), make_key(d[1], j + 1),
+                            make_key(d[2], j + 2), make_key(d[3], j + 3));
             thr = (K == 2 ? m2 : m1) >> KNN_KEY_SHIFT;
         }
     }
@@ -403,7 +431,7 @@ KnnPlan knn_plan(int64_t nq, int64_t nt, int n_cus)
     if (splits < fill)
         splits = fill;
     KnnPlan p = knn_plan_splits(nq, nt, waves, false, splits);
-    p.lazy = p.rows_per_wave >= 3072;
+    p.lazy = p.rows_per_wave >= 8192;
     return p;
 }
 
