@@ -229,20 +229,25 @@ def main():
         # ---- roofline of the dominant kernel (distance kernel), measured live with
         # HIP events on the launch stream, outside the timed region above
         _lib.check(lib.ph_set_profiling(1))
-        ks, ms = [], []
-        a, b = C.c_float(0), C.c_float(0)
+        ks, ms, ov = [], [], []
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
         for r in range(40):
             # a run of back-to-back calls keeps the GPU in the steady state of the timed
             # region; the events of the last call of the run are read
             for f in range(min(F, 8)):
                 _lib.check(fn(qp[f], nq, tp, nt, 2, 0, ip[f], dp[f], kp[f], ratio, sptr))
             _lib.check(lib.ph_knn_last_timing(C.byref(a), C.byref(b)))
+            _lib.check(lib.ph_knn_last_timing_overhead(C.byref(c)))
             if r >= 5:
                 ks.append(a.value)
                 ms.append(b.value)
+                ov.append(c.value)
         _lib.check(lib.ph_set_profiling(0))
-        kernel_ms = float(np.mean(ks))
-        merge_ms = float(np.mean(ms))
+        # an event-to-event interval costs a fixed amount even when empty; it is measured
+        # right behind every call and taken off both kernel figures
+        event_ms = float(np.mean(ov))
+        kernel_ms = float(np.mean(ks)) - event_ms
+        merge_ms = float(np.mean(ms)) - event_ms
         peak_ops = C.c_double(0)
         _lib.check(lib.ph_valu_popcount_peak(4000, C.byref(peak_ops)))
         peak_evals = peak_ops.value / 16.0
@@ -265,6 +270,7 @@ def main():
             "work_per_launch": f"{nq}x{nt} Hamming-256 evals (16 VALU lane-ops each)",
             "kernel_ms": kernel_ms,
             "merge_kernel_ms": merge_ms,
+            "event_interval_overhead_ms": event_ms,
             "peak_source": "measured live: v_xor_b32+v_bcnt_u32_b32 mix, 8 waves/SIMD, /16",
             "peak_spec": 256 * 64 * 2.4e9 / 16 / 1e12,
             "hbm_algorithmic_GBps": 32.0 * (nq + nt) / (kernel_ms * 1e-3) / 1e9,

@@ -191,6 +191,9 @@ ph_status ph_ransac_epnp_hypotheses_batched_dev(const float *d_obj, const float 
  * for the last such call and returns both durations in milliseconds. */
 ph_status ph_set_profiling(int enable);
 ph_status ph_knn_last_timing(float *distance_kernel_ms, float *merge_kernel_ms);
+/* Duration of an empty event-to-event interval recorded right after that call:
+ * the fixed cost the two figures above include on top of the kernels' own time. */
+ph_status ph_knn_last_timing_overhead(float *empty_interval_ms);
 
 /* Sustained VALU rate, in lane-operations per second, of the instruction pair
  * the distance loop is made of (v_xor_b32 with a scalar operand + accumulating

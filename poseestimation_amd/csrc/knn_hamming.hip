@@ -472,6 +472,9 @@ hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const v
         return e;
     if (events && (e = hipEventRecord(events[2], stream)) != hipSuccess)
         return e;
+    // an empty interval right behind: what two event records cost with nothing between
+    if (events && (e = hipEventRecord(events[3], stream)) != hipSuccess)
+        return e;
     return hipSuccess;
 }
 

@@ -83,7 +83,7 @@ struct Context {
     DevBuf in_q, in_t, out_i, out_d, out_k; // staging for the host entry points
     DevBuf pnp_obj, pnp_img, pnp_sub, pnp_models, pnp_counts, pnp_mask, pnp_idx; // RANSAC-EPnP
     bool profiling = false;                 // record events around the distance kernel
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
 };
 
@@ -349,6 +349,19 @@ ph_status ph_set_profiling(int enable)
             PH_HIP(hipEventCreate(&e));
     g_ctx.profiling = enable != 0;
     g_ctx.ev_valid = false;
+    return PH_OK;
+}
+
+ph_status ph_knn_last_timing_overhead(float *empty_interval_ms)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (!g_ctx.ev_valid || !empty_interval_ms)
+        return fail(PH_ERR_INVALID_ARG, "no profiled k-NN call (ph_set_profiling(1) first)");
+    PH_HIP(hipEventSynchronize(g_ctx.ev[3]));
+    PH_HIP(hipEventElapsedTime(empty_interval_ms, g_ctx.ev[2], g_ctx.ev[3]));
     return PH_OK;
 }
 
