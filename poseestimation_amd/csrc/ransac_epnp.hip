@@ -1183,15 +1183,11 @@ static hipError_t launch_solve(const float *d_obj, const float *d_img, CameraK K
                                hipStream_t stream)
 {
     const size_t lds_bytes = (size_t)HPW * LDS_DOUBLES * sizeof(double);
-    static bool configured = false; // opt in to > 64 KiB of dynamic LDS once per process
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)ransac_solve_kernel<HPW>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
-        if (e != hipSuccess)
-            return e;
-        configured = true;
-    }
+    // opt in to > 64 KiB of dynamic LDS (per device, so not cached across calls)
+    hipError_t e = hipFuncSetAttribute((const void *)ransac_solve_kernel<HPW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess)
+        return e;
     ransac_solve_kernel<HPW><<<(n_hyp + HPW - 1) / HPW, 64, lds_bytes, stream>>>(
         d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp, d_models);
     return hipGetLastError();
@@ -1243,15 +1239,10 @@ hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32
                              CameraK K, double *d_model, hipStream_t stream)
 {
     const size_t lds_bytes = (size_t)64 * LDS_DOUBLES * sizeof(double);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)epnp_solve_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
-        if (e != hipSuccess)
-            return e;
-        configured = true;
-    }
+    hipError_t e = hipFuncSetAttribute((const void *)epnp_solve_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess)
+        return e;
     epnp_solve_kernel<<<1, 64, lds_bytes, stream>>>(d_obj, d_img, d_idx, n, K, d_model);
     return hipGetLastError();
 }

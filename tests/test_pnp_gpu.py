@@ -177,3 +177,34 @@ def test_batched_hypotheses_match_oracle(posehip):
         rm, rc = orc.pnp_hypotheses(objs[p], imgs[p], datagen.CAMERA_K, subs[p])
         assert np.array_equal(counts[p * H:(p + 1) * H], rc)
         assert np.abs(models[p * H:(p + 1) * H] - rm).max() < 1e-12
+
+
+def test_scene_to_wireframe_round_trip(posehip):
+    """The whole glue around the pose stage: reference-frame keypoints lifted to 3D on the
+    box (the TODO of src/cereal_box.cpp:292-295), matched pixels of a rotated frame,
+    solvePnPRansac, and the GL model matrix for the wireframe (src/cereal_box.cpp:286)."""
+    import poseestimation_amd as pa
+    from poseestimation_amd import geometry as g
+    rng = np.random.default_rng(7)
+    K = g.camera_matrix()
+    # two faces well in view: with a near-frontal view almost every keypoint lies on one
+    # face and 5-point EPnP samples are coplanar (the degenerate case of the method)
+    M_ref, M_cur = g.model_matrix(0.8), g.model_matrix(1.1)
+    R_ref, t_ref = g.pose_from_model_matrix(M_ref)
+    R_cur, t_cur = g.pose_from_model_matrix(M_cur)
+    # keypoints of the reference frame: random pixels, keep those that hit the box
+    px = rng.random((8000, 2)) * [800, 600]
+    pts3d, hit = g.lift_pixels_to_box(px, R_ref, t_ref, K)
+    pts3d = pts3d[hit][:600]
+    assert len(pts3d) == 600
+    # where those surface points appear in the current frame (+ noise, 20 % wrong matches)
+    img = g.project_cv(pts3d, R_cur, t_cur, K) + rng.normal(0, 0.5, (600, 2))
+    bad = rng.random(600) < 0.2
+    img[bad] = rng.random((int(bad.sum()), 2)) * [800, 600]
+    ok, rvec, tvec, inliers = pa.solvePnPRansac(pts3d, img, K, None, iterationsCount=200)
+    assert ok and len(inliers) >= 0.75 * 600
+    M_est = g.model_matrix_from_pose(rvec, tvec)
+    assert np.abs(M_est - M_cur).max() < 1e-2
+    ok0, r0, t0, inl0, _ = orc.solvepnp_ransac(pts3d, img, K, iterations=200)
+    assert np.array_equal(inliers.ravel(), inl0)
+    assert_same_pose(rvec, tvec, r0, t0)
