@@ -392,6 +392,7 @@ KnnPlan knn_plan_splits(int64_t nq, int64_t nt, int waves, bool lazy, int64_t sp
     if (splits < 1)
         splits = 1;
     int64_t rows = (nt + splits - 1) / splits;
+    rows = (rows + 3) & ~(int64_t)3; // splits start on 128-byte boundaries of the train set
     if (rows > KNN_MAX_ROWS_PER_SPLIT)
         rows = KNN_MAX_ROWS_PER_SPLIT;
     p.rows_per_split = rows;
