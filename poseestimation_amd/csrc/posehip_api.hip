@@ -70,6 +70,42 @@ struct DevBuf {
     }
 };
 
+// Pinned, device-visible host memory that only ever grows.  Kernels write small
+// results straight into it (no device-to-host copy), and host inputs are gathered in
+// it so that one asynchronous copy moves them.
+struct PinBuf {
+    void *p = nullptr;  // host address
+    void *dp = nullptr; // the same memory as the device sees it
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        release();
+        size_t want = std::max(bytes, (size_t)1 << 16);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        e = hipHostGetDevicePointer(&dp, p, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(p);
+            p = dp = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipHostFree(p);
+        p = dp = nullptr;
+        cap = 0;
+    }
+};
+
 struct Context {
     bool ready = false;
     int device = -1;
@@ -80,8 +116,9 @@ struct Context {
     DevBuf best;   // cross-check per-query 64-bit keys
     DevBuf tmp_i;  // cross-check per-train nearest query index
     DevBuf tmp_d;  // cross-check per-train nearest query distance
-    DevBuf in_q, in_t, out_i, out_d, out_k; // staging for the host entry points
-    DevBuf pnp_obj, pnp_img, pnp_sub, pnp_models, pnp_counts, pnp_mask, pnp_idx; // RANSAC-EPnP
+    DevBuf d_in;            // host entry points: device copy of the gathered inputs
+    PinBuf h_in, h_out;     // host entry points: pinned gather buffer / zero-copy results
+    DevBuf pnp_idx;         // RANSAC-EPnP: inlier rows of the refit
     bool profiling = false;                 // record events around the distance kernel
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -181,16 +218,71 @@ ph_status crosscheck_dev_locked(const void *d_q, int64_t nq, const void *d_t, in
     return PH_OK;
 }
 
-// Copies `n` descriptor rows with arbitrary stride into a packed device buffer.
-ph_status upload_rows(DevBuf &buf, const uint8_t *src, int64_t n, size_t step, hipStream_t st)
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+void pack_rows(uint8_t *dst, const uint8_t *src, int64_t n, size_t step)
 {
-    if (n == 0)
-        return PH_OK;
-    PH_HIP(buf.reserve((size_t)n * 32));
-    if (step == 32)
-        PH_HIP(hipMemcpyAsync(buf.p, src, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    if (step == 32) {
+        memcpy(dst, src, (size_t)n * 32);
+        return;
+    }
+    for (int64_t i = 0; i < n; i++)
+        memcpy(dst + i * 32, src + (size_t)i * step, 32);
+}
+
+// Host descriptors -> device: both sets are packed into the pinned gather buffer and
+// moved with ONE asynchronous copy.  On return d_q / d_t point into g_ctx.d_in.
+ph_status upload_descriptors(const uint8_t *q, int64_t nq, size_t q_step, const uint8_t *t,
+                             int64_t nt, size_t t_step, hipStream_t st, const void **d_q,
+                             const void **d_t)
+{
+    const size_t t_off = align256((size_t)nq * 32), total = t_off + (size_t)nt * 32;
+    PH_HIP(g_ctx.h_in.reserve(total));
+    PH_HIP(g_ctx.d_in.reserve(total));
+    pack_rows((uint8_t *)g_ctx.h_in.p, q, nq, q_step);
+    pack_rows((uint8_t *)g_ctx.h_in.p + t_off, t, nt, t_step);
+    PH_HIP(hipMemcpyAsync(g_ctx.d_in.p, g_ctx.h_in.p, total, hipMemcpyHostToDevice, st));
+    *d_q = g_ctx.d_in.p;
+    *d_t = (const uint8_t *)g_ctx.d_in.p + t_off;
+    return PH_OK;
+}
+
+// Results of the host matcher entry points, written by the kernels straight into the
+// pinned result buffer: idx[nq*k] | dist[nq*k] | keep[nq].
+struct HostResult {
+    int32_t *idx, *dist;
+    uint8_t *keep;
+};
+
+enum class MatchMode { Knn, CrossCheck, Ratio };
+
+// The caller holds g_mu, has validated the arguments and nq > 0.  Returns after the
+// stream has been synchronised, with `r` pointing at host-readable results.
+ph_status host_match_locked(const uint8_t *q, int nq, size_t q_step, const uint8_t *t, int nt,
+                            size_t t_step, MatchMode mode, int k, float ratio, HostResult &r)
+{
+    hipStream_t st = g_ctx.stream;
+    const void *d_q = nullptr, *d_t = nullptr;
+    ph_status s = upload_descriptors(q, nq, q_step, t, nt, t_step, st, &d_q, &d_t);
+    if (s != PH_OK)
+        return s;
+    const size_t n_out = (size_t)nq * k;
+    const size_t dist_off = align256(n_out * 4), keep_off = dist_off + align256(n_out * 4);
+    PH_HIP(g_ctx.h_out.reserve(keep_off + (size_t)nq));
+    uint8_t *hb = (uint8_t *)g_ctx.h_out.p, *db = (uint8_t *)g_ctx.h_out.dp;
+    int32_t *d_idx = (int32_t *)db, *d_dist = (int32_t *)(db + dist_off);
+    uint8_t *d_keep = db + keep_off;
+    if (mode == MatchMode::CrossCheck)
+        s = crosscheck_dev_locked(d_q, nq, d_t, nt, d_idx, d_dist, st);
     else
-        PH_HIP(hipMemcpy2DAsync(buf.p, 32, src, step, 32, (size_t)n, hipMemcpyHostToDevice, st));
+        s = knn_dev_locked(d_q, nq, d_t, nt, k, 0, d_idx, d_dist,
+                           mode == MatchMode::Ratio ? d_keep : nullptr, ratio, g_ctx.part, st);
+    if (s != PH_OK)
+        return s;
+    PH_HIP(hipStreamSynchronize(st));
+    r.idx = (int32_t *)hb;
+    r.dist = (int32_t *)(hb + dist_off);
+    r.keep = hb + keep_off;
     return PH_OK;
 }
 
@@ -310,13 +402,12 @@ void ph_shutdown(void)
         return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipStreamSynchronize(g_ctx.stream);
-    DevBuf *all[] = {&g_ctx.part,      &g_ctx.part2,      &g_ctx.best,       &g_ctx.tmp_i,
-                     &g_ctx.tmp_d,     &g_ctx.in_q,       &g_ctx.in_t,       &g_ctx.out_i,
-                     &g_ctx.out_d,     &g_ctx.out_k,      &g_ctx.pnp_obj,    &g_ctx.pnp_img,
-                     &g_ctx.pnp_sub,   &g_ctx.pnp_models, &g_ctx.pnp_counts, &g_ctx.pnp_mask,
-                     &g_ctx.pnp_idx};
+    DevBuf *all[] = {&g_ctx.part,  &g_ctx.part2, &g_ctx.best,   &g_ctx.tmp_i,
+                     &g_ctx.tmp_d, &g_ctx.d_in,  &g_ctx.pnp_idx};
     for (DevBuf *b : all)
         b->release();
+    g_ctx.h_in.release();
+    g_ctx.h_out.release();
     (void)hipStreamDestroy(g_ctx.stream);
     for (hipEvent_t e : g_ctx.ev)
         if (e)
@@ -475,156 +566,73 @@ ph_status ph_knn_hamming256(const uint8_t *query, int nq, size_t q_step, const u
         return PH_OK;
     if (!out_idx || !out_dist)
         return fail(PH_ERR_INVALID_ARG, "null output pointer");
-    hipStream_t st = g_ctx.stream;
-    if ((s = upload_rows(g_ctx.in_q, query, nq, q_step, st)) != PH_OK)
+    HostResult r;
+    if ((s = host_match_locked(query, nq, q_step, train, nt, t_step, MatchMode::Knn, k, 0.f, r)) !=
+        PH_OK)
         return s;
-    if ((s = upload_rows(g_ctx.in_t, train, nt, t_step, st)) != PH_OK)
-        return s;
-    const size_t ob = (size_t)nq * k * sizeof(int32_t);
-    PH_HIP(g_ctx.out_i.reserve(ob));
-    PH_HIP(g_ctx.out_d.reserve(ob));
-    s = knn_dev_locked(g_ctx.in_q.p, nq, g_ctx.in_t.p, nt, k, 0, (int32_t *)g_ctx.out_i.p,
-                       (int32_t *)g_ctx.out_d.p, nullptr, 0.f, g_ctx.part, st);
-    if (s != PH_OK)
-        return s;
-    PH_HIP(hipMemcpyAsync(out_idx, g_ctx.out_i.p, ob, hipMemcpyDeviceToHost, st));
-    PH_HIP(hipMemcpyAsync(out_dist, g_ctx.out_d.p, ob, hipMemcpyDeviceToHost, st));
-    PH_HIP(hipStreamSynchronize(st));
+    memcpy(out_idx, r.idx, (size_t)nq * k * sizeof(int32_t));
+    memcpy(out_dist, r.dist, (size_t)nq * k * sizeof(int32_t));
     return PH_OK;
 }
 
-ph_status ph_match_hamming256(const uint8_t *query, int nq, size_t q_step, const uint8_t *train,
-                              int nt, size_t t_step, ph_dmatch *out, int *n_out)
+namespace {
+// Shared tail of the three match() flavours: one DMatch per kept query, ascending.
+ph_status host_match_list(const uint8_t *query, int nq, size_t q_step, const uint8_t *train, int nt,
+                          size_t t_step, MatchMode mode, float ratio, ph_dmatch *out, int *n_out)
 {
     if (!n_out)
         return fail(PH_ERR_INVALID_ARG, "n_out is null");
     *n_out = 0;
-    if (nq > 0 && nt > 0 && !out)
-        return fail(PH_ERR_INVALID_ARG, "null output pointer");
-    std::vector<int32_t> idx((size_t)std::max(nq, 0)), dist((size_t)std::max(nq, 0));
-    ph_status s = ph_knn_hamming256(query, nq, q_step, train, nt, t_step, 1, idx.data(),
-                                    dist.data());
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
     if (s != PH_OK)
+        return s;
+    if ((s = check_host_args(query, nq, q_step, train, nt, t_step)) != PH_OK)
+        return s;
+    if (nq == 0 || nt == 0)
+        return PH_OK; // OpenCV clears the match list
+    if (!out)
+        return fail(PH_ERR_INVALID_ARG, "null output pointer");
+    const int k = mode == MatchMode::Ratio ? 2 : 1;
+    HostResult r;
+    if ((s = host_match_locked(query, nq, q_step, train, nt, t_step, mode, k, ratio, r)) != PH_OK)
         return s;
     int n = 0;
     for (int i = 0; i < nq; i++) {
-        if (idx[i] < 0)
+        const bool kept = mode == MatchMode::Ratio ? r.keep[i] != 0 : r.idx[(size_t)i * k] >= 0;
+        if (!kept)
             continue;
         out[n].queryIdx = i;
-        out[n].trainIdx = idx[i];
+        out[n].trainIdx = r.idx[(size_t)i * k];
         out[n].imgIdx = 0;
-        out[n].distance = (float)dist[i];
+        out[n].distance = (float)r.dist[(size_t)i * k];
         n++;
     }
     *n_out = n;
     return PH_OK;
+}
+} // namespace
+
+ph_status ph_match_hamming256(const uint8_t *query, int nq, size_t q_step, const uint8_t *train,
+                              int nt, size_t t_step, ph_dmatch *out, int *n_out)
+{
+    return host_match_list(query, nq, q_step, train, nt, t_step, MatchMode::Knn, 0.f, out, n_out);
 }
 
 ph_status ph_match_crosscheck_hamming256(const uint8_t *query, int nq, size_t q_step,
                                          const uint8_t *train, int nt, size_t t_step,
                                          ph_dmatch *out, int *n_out)
 {
-    if (!n_out)
-        return fail(PH_ERR_INVALID_ARG, "n_out is null");
-    *n_out = 0;
-    std::vector<int32_t> idx, dist;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        ph_status s = ensure_ready();
-        if (s != PH_OK)
-            return s;
-        if ((s = check_host_args(query, nq, q_step, train, nt, t_step)) != PH_OK)
-            return s;
-        if (nq == 0 || nt == 0)
-            return PH_OK;
-        if (!out)
-            return fail(PH_ERR_INVALID_ARG, "null output pointer");
-        hipStream_t st = g_ctx.stream;
-        if ((s = upload_rows(g_ctx.in_q, query, nq, q_step, st)) != PH_OK)
-            return s;
-        if ((s = upload_rows(g_ctx.in_t, train, nt, t_step, st)) != PH_OK)
-            return s;
-        const size_t ob = (size_t)nq * sizeof(int32_t);
-        PH_HIP(g_ctx.out_i.reserve(ob));
-        PH_HIP(g_ctx.out_d.reserve(ob));
-        s = crosscheck_dev_locked(g_ctx.in_q.p, nq, g_ctx.in_t.p, nt, (int32_t *)g_ctx.out_i.p,
-                                  (int32_t *)g_ctx.out_d.p, st);
-        if (s != PH_OK)
-            return s;
-        idx.resize((size_t)nq);
-        dist.resize((size_t)nq);
-        PH_HIP(hipMemcpyAsync(idx.data(), g_ctx.out_i.p, ob, hipMemcpyDeviceToHost, st));
-        PH_HIP(hipMemcpyAsync(dist.data(), g_ctx.out_d.p, ob, hipMemcpyDeviceToHost, st));
-        PH_HIP(hipStreamSynchronize(st));
-    }
-    int n = 0;
-    for (int i = 0; i < nq; i++) {
-        if (idx[i] < 0)
-            continue;
-        out[n].queryIdx = i;
-        out[n].trainIdx = idx[i];
-        out[n].imgIdx = 0;
-        out[n].distance = (float)dist[i];
-        n++;
-    }
-    *n_out = n;
-    return PH_OK;
+    return host_match_list(query, nq, q_step, train, nt, t_step, MatchMode::CrossCheck, 0.f, out,
+                           n_out);
 }
 
 ph_status ph_knn2_ratio_hamming256(const uint8_t *query, int nq, size_t q_step,
                                    const uint8_t *train, int nt, size_t t_step, float ratio,
                                    ph_dmatch *out, int *n_out)
 {
-    if (!n_out)
-        return fail(PH_ERR_INVALID_ARG, "n_out is null");
-    *n_out = 0;
-    std::vector<int32_t> idx, dist;
-    std::vector<uint8_t> keep;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        ph_status s = ensure_ready();
-        if (s != PH_OK)
-            return s;
-        if ((s = check_host_args(query, nq, q_step, train, nt, t_step)) != PH_OK)
-            return s;
-        if (nq == 0 || nt == 0)
-            return PH_OK;
-        if (!out)
-            return fail(PH_ERR_INVALID_ARG, "null output pointer");
-        hipStream_t st = g_ctx.stream;
-        if ((s = upload_rows(g_ctx.in_q, query, nq, q_step, st)) != PH_OK)
-            return s;
-        if ((s = upload_rows(g_ctx.in_t, train, nt, t_step, st)) != PH_OK)
-            return s;
-        const size_t ob = (size_t)nq * 2 * sizeof(int32_t);
-        PH_HIP(g_ctx.out_i.reserve(ob));
-        PH_HIP(g_ctx.out_d.reserve(ob));
-        PH_HIP(g_ctx.out_k.reserve((size_t)nq));
-        s = knn_dev_locked(g_ctx.in_q.p, nq, g_ctx.in_t.p, nt, 2, 0, (int32_t *)g_ctx.out_i.p,
-                           (int32_t *)g_ctx.out_d.p, (uint8_t *)g_ctx.out_k.p, ratio, g_ctx.part,
-                           st);
-        if (s != PH_OK)
-            return s;
-        idx.resize((size_t)nq * 2);
-        dist.resize((size_t)nq * 2);
-        keep.resize((size_t)nq);
-        PH_HIP(hipMemcpyAsync(idx.data(), g_ctx.out_i.p, ob, hipMemcpyDeviceToHost, st));
-        PH_HIP(hipMemcpyAsync(dist.data(), g_ctx.out_d.p, ob, hipMemcpyDeviceToHost, st));
-        PH_HIP(hipMemcpyAsync(keep.data(), g_ctx.out_k.p, (size_t)nq, hipMemcpyDeviceToHost, st));
-        PH_HIP(hipStreamSynchronize(st));
-    }
-    int n = 0;
-    for (int i = 0; i < nq; i++) {
-        if (!keep[i])
-            continue;
-        out[n].queryIdx = i;
-        out[n].trainIdx = idx[2 * (size_t)i];
-        out[n].imgIdx = 0;
-        out[n].distance = (float)dist[2 * (size_t)i];
-        n++;
-    }
-    *n_out = n;
-    return PH_OK;
+    return host_match_list(query, nq, q_step, train, nt, t_step, MatchMode::Ratio, ratio, out,
+                           n_out);
 }
 
 ph_status ph_ransac_subsets(uint64_t rng_state, int n_points, int n_subsets, int32_t *out)
@@ -682,6 +690,35 @@ ph_status ph_ransac_epnp_hypotheses_batched_dev(const float *d_obj, const float 
     return PH_OK;
 }
 
+namespace {
+// Host correspondences (and, for RANSAC, the subset table) -> device with one copy.
+// Layout of g_ctx.d_in: obj[n*3] f32 | img[n*2] f32 | subsets[n_sub*5] i32.
+struct PnpDev {
+    const float *obj, *img;
+    const int32_t *subsets;
+};
+
+ph_status upload_pnp(const float *obj, const float *img, int n, const int32_t *subsets,
+                     size_t n_sub, hipStream_t st, PnpDev &d)
+{
+    const size_t img_off = align256((size_t)n * 12), sub_off = img_off + align256((size_t)n * 8);
+    const size_t total = sub_off + n_sub * 5 * sizeof(int32_t);
+    PH_HIP(g_ctx.h_in.reserve(total));
+    PH_HIP(g_ctx.d_in.reserve(total));
+    uint8_t *h = (uint8_t *)g_ctx.h_in.p;
+    memcpy(h, obj, (size_t)n * 12);
+    memcpy(h + img_off, img, (size_t)n * 8);
+    if (n_sub)
+        memcpy(h + sub_off, subsets, n_sub * 5 * sizeof(int32_t));
+    PH_HIP(hipMemcpyAsync(g_ctx.d_in.p, h, total, hipMemcpyHostToDevice, st));
+    const uint8_t *db = (const uint8_t *)g_ctx.d_in.p;
+    d.obj = (const float *)db;
+    d.img = (const float *)(db + img_off);
+    d.subsets = (const int32_t *)(db + sub_off);
+    return PH_OK;
+}
+} // namespace
+
 ph_status ph_solvepnp_epnp(const float *obj, const float *img, int n, const double *K,
                            double *rvec, double *tvec)
 {
@@ -694,16 +731,13 @@ ph_status ph_solvepnp_epnp(const float *obj, const float *img, int n, const doub
     if (n < 4 || !rvec || !tvec)
         return fail(PH_ERR_INVALID_ARG, "EPnP needs >= 4 correspondences and output pointers");
     hipStream_t st = g_ctx.stream;
-    PH_HIP(g_ctx.pnp_obj.reserve((size_t)n * 12));
-    PH_HIP(g_ctx.pnp_img.reserve((size_t)n * 8));
-    PH_HIP(g_ctx.pnp_models.reserve(6 * sizeof(double)));
-    PH_HIP(hipMemcpyAsync(g_ctx.pnp_obj.p, obj, (size_t)n * 12, hipMemcpyHostToDevice, st));
-    PH_HIP(hipMemcpyAsync(g_ctx.pnp_img.p, img, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    PH_HIP(epnp_solve_launch((const float *)g_ctx.pnp_obj.p, (const float *)g_ctx.pnp_img.p,
-                             nullptr, n, camera_of(K), (double *)g_ctx.pnp_models.p, st));
-    double m[6];
-    PH_HIP(hipMemcpyAsync(m, g_ctx.pnp_models.p, sizeof(m), hipMemcpyDeviceToHost, st));
+    PnpDev d;
+    if ((s = upload_pnp(obj, img, n, nullptr, 0, st, d)) != PH_OK)
+        return s;
+    PH_HIP(g_ctx.h_out.reserve(6 * sizeof(double)));
+    PH_HIP(epnp_solve_launch(d.obj, d.img, nullptr, n, camera_of(K), (double *)g_ctx.h_out.dp, st));
     PH_HIP(hipStreamSynchronize(st));
+    const double *m = (const double *)g_ctx.h_out.p;
     memcpy(rvec, m, 3 * sizeof(double));
     memcpy(tvec, m + 3, 3 * sizeof(double));
     return PH_OK;
@@ -739,18 +773,15 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
     const double thr = reproj_err;
     const float thr2 = (float)(thr * thr);
     hipStream_t st = g_ctx.stream;
-    PH_HIP(g_ctx.pnp_obj.reserve((size_t)n * 12));
-    PH_HIP(g_ctx.pnp_img.reserve((size_t)n * 8));
-    PH_HIP(hipMemcpyAsync(g_ctx.pnp_obj.p, obj, (size_t)n * 12, hipMemcpyHostToDevice, st));
-    PH_HIP(hipMemcpyAsync(g_ctx.pnp_img.p, img, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    const float *d_obj = (const float *)g_ctx.pnp_obj.p, *d_img = (const float *)g_ctx.pnp_img.p;
-    PH_HIP(g_ctx.pnp_models.reserve(6 * sizeof(double)));
 
     if (n == model_points) { // run(): count == modelPoints -> one solve, every point an inlier
-        PH_HIP(epnp_solve_launch(d_obj, d_img, nullptr, n, cam, (double *)g_ctx.pnp_models.p, st));
-        double m[6];
-        PH_HIP(hipMemcpyAsync(m, g_ctx.pnp_models.p, sizeof(m), hipMemcpyDeviceToHost, st));
+        PnpDev d;
+        if ((s = upload_pnp(obj, img, n, nullptr, 0, st, d)) != PH_OK)
+            return s;
+        PH_HIP(g_ctx.h_out.reserve(6 * sizeof(double)));
+        PH_HIP(epnp_solve_launch(d.obj, d.img, nullptr, n, cam, (double *)g_ctx.h_out.dp, st));
         PH_HIP(hipStreamSynchronize(st));
+        const double *m = (const double *)g_ctx.h_out.p;
         memcpy(rvec, m, 3 * sizeof(double));
         memcpy(tvec, m + 3, 3 * sizeof(double));
         if (inliers)
@@ -770,26 +801,26 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
     const int total = niters;
     std::vector<int32_t> subsets((size_t)total * 5);
     draw_subsets(rng_state, n, total, subsets.data());
-    PH_HIP(g_ctx.pnp_sub.reserve(subsets.size() * sizeof(int32_t)));
-    PH_HIP(hipMemcpyAsync(g_ctx.pnp_sub.p, subsets.data(), subsets.size() * sizeof(int32_t),
-                          hipMemcpyHostToDevice, st));
-    const int chunk = 4096;
-    PH_HIP(g_ctx.pnp_models.reserve((size_t)std::min(total, chunk) * 6 * sizeof(double) + 64));
-    PH_HIP(g_ctx.pnp_counts.reserve((size_t)std::min(total, chunk) * sizeof(int32_t)));
-    std::vector<double> models((size_t)std::min(total, chunk) * 6);
-    std::vector<int32_t> counts((size_t)std::min(total, chunk));
+    PnpDev d;
+    if ((s = upload_pnp(obj, img, n, subsets.data(), (size_t)total, st, d)) != PH_OK)
+        return s;
+    // pinned results, written by the kernels: models | counts | mask | refit model
+    const int chunk = 4096, cmax = std::min(total, chunk);
+    const size_t counts_off = align256((size_t)cmax * 6 * sizeof(double));
+    const size_t mask_off = counts_off + align256((size_t)cmax * sizeof(int32_t));
+    const size_t best_off = mask_off + align256((size_t)n);
+    const size_t refit_off = best_off + 256;
+    PH_HIP(g_ctx.h_out.reserve(refit_off + 256));
+    uint8_t *hb = (uint8_t *)g_ctx.h_out.p, *db = (uint8_t *)g_ctx.h_out.dp;
+    const double *models = (const double *)hb;
+    const int32_t *counts = (const int32_t *)(hb + counts_off);
     int max_good = 0, iter = 0;
     double best[6] = {0, 0, 0, 0, 0, 0};
     for (int base = 0; base < total && base < niters; base += chunk) {
         const int m = std::min(chunk, total - base);
-        PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, cam,
-                                        (const int32_t *)g_ctx.pnp_sub.p + (size_t)base * 5, nullptr,
-                                        1, m, thr2, (double *)g_ctx.pnp_models.p,
-                                        (int32_t *)g_ctx.pnp_counts.p, g_ctx.n_cus, st));
-        PH_HIP(hipMemcpyAsync(models.data(), g_ctx.pnp_models.p, (size_t)m * 6 * sizeof(double),
-                              hipMemcpyDeviceToHost, st));
-        PH_HIP(hipMemcpyAsync(counts.data(), g_ctx.pnp_counts.p, (size_t)m * sizeof(int32_t),
-                              hipMemcpyDeviceToHost, st));
+        PH_HIP(ransac_hypotheses_launch(d.obj, d.img, n, cam, d.subsets + (size_t)base * 5, nullptr,
+                                        1, m, thr2, (double *)db, (int32_t *)(db + counts_off),
+                                        g_ctx.n_cus, st));
         PH_HIP(hipStreamSynchronize(st));
         for (iter = base; iter < base + m && iter < niters; iter++) {
             const int good = counts[iter - base];
@@ -807,13 +838,11 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
         return PH_OK;
     }
     // inlier mask of the best model, then one EPnP solve over its inliers
-    PH_HIP(g_ctx.pnp_mask.reserve((size_t)n));
-    PH_HIP(hipMemcpyAsync(g_ctx.pnp_models.p, best, sizeof(best), hipMemcpyHostToDevice, st));
-    PH_HIP(inlier_mask_launch(d_obj, d_img, n, cam, (const double *)g_ctx.pnp_models.p, thr2,
-                              (uint8_t *)g_ctx.pnp_mask.p, st));
-    std::vector<uint8_t> mask((size_t)n);
-    PH_HIP(hipMemcpyAsync(mask.data(), g_ctx.pnp_mask.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    memcpy(hb + best_off, best, sizeof(best)); // the device reads the model from pinned memory
+    PH_HIP(inlier_mask_launch(d.obj, d.img, n, cam, (const double *)(db + best_off), thr2,
+                              db + mask_off, st));
     PH_HIP(hipStreamSynchronize(st));
+    const uint8_t *mask = hb + mask_off;
     std::vector<int32_t> idx;
     idx.reserve((size_t)max_good);
     for (int i = 0; i < n; i++)
@@ -826,14 +855,18 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
         *found = 0;
         return PH_OK;
     }
+    // the subset table is no longer needed: the inlier list goes through the same
+    // pinned area (behind obj | img) and one copy
     PH_HIP(g_ctx.pnp_idx.reserve((size_t)k * sizeof(int32_t)));
-    PH_HIP(hipMemcpyAsync(g_ctx.pnp_idx.p, idx.data(), (size_t)k * sizeof(int32_t),
-                          hipMemcpyHostToDevice, st));
-    PH_HIP(epnp_solve_launch(d_obj, d_img, (const int32_t *)g_ctx.pnp_idx.p, k, cam,
-                             (double *)g_ctx.pnp_models.p, st));
-    double m6[6];
-    PH_HIP(hipMemcpyAsync(m6, g_ctx.pnp_models.p, sizeof(m6), hipMemcpyDeviceToHost, st));
+    const size_t idx_off = align256((size_t)n * 12) + align256((size_t)n * 8);
+    PH_HIP(g_ctx.h_in.reserve(idx_off + (size_t)k * sizeof(int32_t)));
+    memcpy((uint8_t *)g_ctx.h_in.p + idx_off, idx.data(), (size_t)k * sizeof(int32_t));
+    PH_HIP(hipMemcpyAsync(g_ctx.pnp_idx.p, (uint8_t *)g_ctx.h_in.p + idx_off,
+                          (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    PH_HIP(epnp_solve_launch(d.obj, d.img, (const int32_t *)g_ctx.pnp_idx.p, k, cam,
+                             (double *)(db + refit_off), st));
     PH_HIP(hipStreamSynchronize(st));
+    const double *m6 = (const double *)(hb + refit_off);
     memcpy(rvec, m6, 3 * sizeof(double));
     memcpy(tvec, m6 + 3, 3 * sizeof(double));
     if (inliers)
