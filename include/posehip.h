@@ -110,11 +110,30 @@ ph_status ph_min_dist_filter(const ph_dmatch *m, int n, ph_dmatch *out, int *n_o
  * report global indices).  d_keep may be NULL; otherwise k must be 2 and
  * d_keep[i] (one byte per query) is set to 1 iff the ratio test with `ratio`
  * passes.  Enqueues on `stream` (a hipStream_t, NULL = library stream) and
- * returns without waiting; the library workspace is reused by the next call,
- * so calls on different streams must not overlap. */
+ * returns without waiting.  The library workspace is shared: a call on another
+ * stream than the previous one is ordered after that one's work (calls never
+ * run concurrently with each other). */
 ph_status ph_knn_hamming256_dev(const void *d_query, int64_t nq, const void *d_train, int64_t nt,
                                 int k, int32_t train_index_base, int32_t *d_out_idx,
                                 int32_t *d_out_dist, uint8_t *d_keep, float ratio, void *stream);
+
+/* A batch of frames in one launch: frame f matches query rows
+ * [q_offsets[f], q_offsets[f+1]) of d_query against train rows
+ * [t_offsets[f], t_offsets[f+1]) of d_train, i.e. n_frames calls of
+ * matcher->knnMatch(descriptors, descriptorsOld, ...) as the reference issues one
+ * per rendered frame (src/cereal_box.cpp:341-344), fused so that small frames fill
+ * the GPU.  q_offsets / t_offsets: HOST arrays of n_frames + 1 ascending row
+ * offsets (copied before the call returns).  d_query and d_train may be the same
+ * buffer (frame f against frame f-1 of one descriptor stream).  Outputs are
+ * indexed by query row of d_query (rows q_offsets[0] .. q_offsets[n_frames]);
+ * train indices are relative to the frame's first train row.  A frame without
+ * train rows yields PH_NO_MATCH_* rows.  Train offsets that are multiples of 4
+ * rows run fastest.  Otherwise as ph_knn_hamming256_dev. */
+ph_status ph_knn_hamming256_frames_dev(const void *d_query, const int32_t *q_offsets,
+                                       const void *d_train, const int32_t *t_offsets,
+                                       int n_frames, int k, int32_t *d_out_idx,
+                                       int32_t *d_out_dist, uint8_t *d_keep, float ratio,
+                                       void *stream);
 
 /* Merge per-shard k-NN candidate lists (the step after the all-gather of a
  * train-sharded search).  d_cand_idx / d_cand_dist: [n_shards][nq][k], shards

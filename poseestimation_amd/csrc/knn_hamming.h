@@ -32,6 +32,21 @@ hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const v
                       int32_t *d_out_dist, uint8_t *d_keep, float ratio, hipStream_t stream,
                       hipEvent_t *events = nullptr);
 
+// A batch of independent matching problems in one launch: frame f matches query
+// rows [q_off[f], q_off[f+1]) against train rows [t_off[f], t_off[f+1]) (device
+// arrays of n_frames + 1 ascending offsets).  Outputs are indexed by query row over
+// the whole batch; train indices are local to the frame.  max_nq / max_nt bound
+// the frames' sizes (the launch grid and the split count come from them).
+KnnPlan knn_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int64_t total_nq, int n_cus);
+hipError_t knn_frames_launch(const KnnPlan &p, const void *d_query, const int32_t *d_q_off,
+                             const void *d_train, const int32_t *d_t_off, int n_frames,
+                             int64_t total_nq, int k, uint32_t *d_part, int32_t *d_out_idx,
+                             int32_t *d_out_dist, uint8_t *d_keep, float ratio,
+                             hipStream_t stream, hipEvent_t *events = nullptr);
+
+// Train rows per split of a frame with nt train rows under plan p.
+int64_t frame_rows_per_split(int64_t nt, const KnnPlan &p);
+
 // Sustained rate of the inner loop's instruction mix (v_xor_b32 with an SGPR
 // operand + accumulating v_bcnt_u32_b32) with 8 waves per SIMD on every CU:
 // the measured denominator of the matcher's roofline.  Blocks until done.

@@ -172,10 +172,15 @@ template <typename K> __device__ __forceinline__ void merge_pairs(K &a1, K &a2, 
 // (one per lane) and each stream their own slice of the workgroup's train
 // split; the per-wave key pairs are folded through LDS and the workgroup
 // writes one pair per query: part[split][rank 0/1][nq], keys local to the split.
+//
+// query / train / nq / nt describe ONE matching problem; its query row i is row
+// part_row0 + i of the part arrays, which are part_stride rows long.
 template <bool LAZY, int K>
-__global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_kernel(
-    const uint4 *__restrict__ query, const uint4 *__restrict__ train, int64_t nq, int64_t nt,
-    int64_t rows_per_split, int rows_per_wave, uint32_t *__restrict__ part)
+__device__ __forceinline__ void knn_partial_body(const uint4 *__restrict__ query,
+                                                 const uint4 *__restrict__ train, int64_t nq,
+                                                 int64_t nt, int64_t rows_per_split,
+                                                 int rows_per_wave, uint32_t *__restrict__ part,
+                                                 int64_t part_row0, int64_t part_stride)
 {
     __shared__ uint32_t lds[2][KNN_MAX_WAVES][64];
     const int lane = threadIdx.x & 63;
@@ -232,10 +237,56 @@ __global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_kernel(
             merge_pairs(m1, m2, lds[0][w][lane], lds[1][w][lane]);
     }
     if (qi < nq) {
-        uint32_t *p1 = part + ((int64_t)split * 2) * nq;
+        uint32_t *p1 = part + ((int64_t)split * 2) * part_stride + part_row0;
         p1[qi] = m1;
-        p1[nq + qi] = m2;
+        p1[part_stride + qi] = m2;
     }
+}
+
+template <bool LAZY, int K>
+__global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_kernel(
+    const uint4 *__restrict__ query, const uint4 *__restrict__ train, int64_t nq, int64_t nt,
+    int64_t rows_per_split, int rows_per_wave, uint32_t *__restrict__ part)
+{
+    knn_partial_body<LAZY, K>(query, train, nq, nt, rows_per_split, rows_per_wave, part, 0, nq);
+}
+
+// Train rows per split / per wave of a frame in a batch of frames: every frame uses
+// the launch's split count, so its split length follows from its own train count
+// (multiples of 4 rows keep the 64-byte scalar loads inside cache lines).
+struct FrameGeom {
+    int64_t rows_per_split;
+    int rows_per_wave;
+};
+
+__host__ __device__ inline FrameGeom frame_geom(int64_t nt, int n_splits, int waves)
+{
+    int64_t rows = (nt + n_splits - 1) / n_splits;
+    rows = (rows + 3) & ~(int64_t)3;
+    if (rows < 4)
+        rows = 4;
+    int64_t rw = (rows + waves - 1) / waves;
+    rw = (rw + 3) & ~(int64_t)3;
+    return FrameGeom{rows, (int)rw};
+}
+
+// A batch of independent matching problems ("frames") in one launch: frame
+// f = blockIdx.z matches query rows [q_off[f], q_off[f+1]) against train rows
+// [t_off[f], t_off[f+1]).  Workgroups beyond a frame's own query blocks leave at once.
+template <bool LAZY, int K>
+__global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_frames_kernel(
+    const uint4 *__restrict__ query, const uint4 *__restrict__ train,
+    const int32_t *__restrict__ q_off, const int32_t *__restrict__ t_off, int64_t total_nq,
+    uint32_t *__restrict__ part)
+{
+    const int f = blockIdx.z;
+    const int64_t q0 = q_off[f], nq = q_off[f + 1] - q0;
+    const int64_t t0 = t_off[f], nt = t_off[f + 1] - t0;
+    if ((int64_t)blockIdx.x * 64 >= nq)
+        return;
+    const FrameGeom g = frame_geom(nt, (int)gridDim.y, (int)(blockDim.x >> 6));
+    knn_partial_body<LAZY, K>(query + 2 * q0, train + 2 * t0, nq, nt, g.rows_per_split,
+                              g.rows_per_wave, part, q0, total_nq);
 }
 
 // Folds the per-split keys into the final k-NN rows.  Keys become
@@ -243,19 +294,20 @@ __global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_kernel(
 // answer (lowest train index among equal distances) whatever the fold order.
 // A workgroup covers 64 queries; its 4 waves take the splits round-robin and
 // are folded through LDS.
-__global__ __launch_bounds__(256) void knn_merge_kernel(const uint32_t *__restrict__ part,
-                                                        int64_t nq, int n_splits,
-                                                        int64_t rows_per_split, int k,
-                                                        int32_t index_base,
-                                                        int32_t *__restrict__ out_idx,
-                                                        int32_t *__restrict__ out_dist,
-                                                        uint8_t *__restrict__ keep, float ratio)
+// Here nq counts the rows of the part and output arrays and the workgroup's 64
+// query rows start at row0; rows at or beyond row_end are not touched.
+__device__ __forceinline__ void knn_merge_body(const uint32_t *__restrict__ part, int64_t nq,
+                                               int64_t row0, int64_t row_end, int n_splits,
+                                               int64_t rows_per_split, int k, int32_t index_base,
+                                               int32_t *__restrict__ out_idx,
+                                               int32_t *__restrict__ out_dist,
+                                               uint8_t *__restrict__ keep, float ratio)
 {
     __shared__ uint64_t lds[2][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t qi = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t qi = row0 + lane;
     uint64_t b1 = ~0ull, b2 = ~0ull;
-    if (qi < nq) {
+    if (qi < row_end) {
         const uint32_t mask = (1u << KNN_KEY_SHIFT) - 1;
         for (int s = wave; s < n_splits; s += 4) {
             const uint32_t *p = part + ((int64_t)s * 2) * nq;
@@ -273,7 +325,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint32_t *__restri
     lds[0][wave][lane] = b1;
     lds[1][wave][lane] = b2;
     __syncthreads();
-    if (wave != 0 || qi >= nq)
+    if (wave != 0 || qi >= row_end)
         return;
     for (int w = 1; w < 4; w++)
         merge_pairs(b1, b2, lds[0][w][lane], lds[1][w][lane]);
@@ -290,6 +342,35 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint32_t *__restri
     *reinterpret_cast<int2 *>(out_dist + 2 * qi) = make_int2(d1, d2);
     if (keep)
         keep[qi] = (i1 >= 0 && i2 >= 0 && (float)d1 < ratio * (float)d2) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void knn_merge_kernel(const uint32_t *__restrict__ part,
+                                                        int64_t nq, int n_splits,
+                                                        int64_t rows_per_split, int k,
+                                                        int32_t index_base,
+                                                        int32_t *__restrict__ out_idx,
+                                                        int32_t *__restrict__ out_dist,
+                                                        uint8_t *__restrict__ keep, float ratio)
+{
+    knn_merge_body(part, nq, (int64_t)blockIdx.x * 64, nq, n_splits, rows_per_split, k,
+                   index_base, out_idx, out_dist, keep, ratio);
+}
+
+// Merge for a batch of frames (grid.y = frame); train indices are local to the frame.
+__global__ __launch_bounds__(256) void knn_merge_frames_kernel(
+    const uint32_t *__restrict__ part, const int32_t *__restrict__ q_off,
+    const int32_t *__restrict__ t_off, int64_t total_nq, int n_splits, int waves, int k,
+    int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist, uint8_t *__restrict__ keep,
+    float ratio)
+{
+    const int f = blockIdx.y;
+    const int64_t q0 = q_off[f], q1 = q_off[f + 1];
+    const int64_t row0 = q0 + (int64_t)blockIdx.x * 64;
+    if (row0 >= q1)
+        return;
+    const FrameGeom g = frame_geom((int64_t)t_off[f + 1] - t_off[f], n_splits, waves);
+    knn_merge_body(part, total_nq, row0, q1, n_splits, g.rows_per_split, k, 0, out_idx, out_dist,
+                   keep, ratio);
 }
 
 // Merge of all-gathered per-shard candidate rows ([shard][nq][k], global
@@ -475,6 +556,64 @@ hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const v
     if (events && (e = hipEventRecord(events[2], stream)) != hipSuccess)
         return e;
     // an empty interval right behind: what two event records cost with nothing between
+    if (events && (e = hipEventRecord(events[3], stream)) != hipSuccess)
+        return e;
+    return hipSuccess;
+}
+
+KnnPlan knn_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int64_t total_nq, int n_cus)
+{
+    // Plan as for one problem with all the frames' query blocks and the longest train set.
+    const int64_t q_blocks = (max_nq + 63) / 64;
+    KnnPlan p = knn_plan(q_blocks * 64 * n_frames, max_nt, n_cus);
+    p.q_blocks = q_blocks;
+    p.part_bytes = (size_t)p.n_splits * 2 * (size_t)total_nq * sizeof(uint32_t);
+    return p;
+}
+
+int64_t frame_rows_per_split(int64_t nt, const KnnPlan &p)
+{
+    return frame_geom(nt, p.n_splits, p.waves).rows_per_split;
+}
+
+hipError_t knn_frames_launch(const KnnPlan &p, const void *d_query, const int32_t *d_q_off,
+                             const void *d_train, const int32_t *d_t_off, int n_frames,
+                             int64_t total_nq, int k, uint32_t *d_part, int32_t *d_out_idx,
+                             int32_t *d_out_dist, uint8_t *d_keep, float ratio,
+                             hipStream_t stream, hipEvent_t *events)
+{
+    if (p.waves < 1 || p.waves > KNN_MAX_WAVES || p.n_splits < 1 || p.n_splits > 65535 ||
+        n_frames < 1 || n_frames > 65535 || p.q_blocks < 1)
+        return hipErrorInvalidValue;
+    dim3 grid((unsigned)p.q_blocks, (unsigned)p.n_splits, (unsigned)n_frames);
+    hipError_t e;
+    if (events && (e = hipEventRecord(events[0], stream)) != hipSuccess)
+        return e;
+    const uint4 *q4 = (const uint4 *)d_query, *t4 = (const uint4 *)d_train;
+    const int threads = p.waves * 64;
+    if (p.lazy && k == 2)
+        knn_partial_frames_kernel<true, 2><<<grid, threads, 0, stream>>>(q4, t4, d_q_off, d_t_off,
+                                                                         total_nq, d_part);
+    else if (p.lazy)
+        knn_partial_frames_kernel<true, 1><<<grid, threads, 0, stream>>>(q4, t4, d_q_off, d_t_off,
+                                                                         total_nq, d_part);
+    else if (k == 2)
+        knn_partial_frames_kernel<false, 2><<<grid, threads, 0, stream>>>(q4, t4, d_q_off, d_t_off,
+                                                                          total_nq, d_part);
+    else
+        knn_partial_frames_kernel<false, 1><<<grid, threads, 0, stream>>>(q4, t4, d_q_off, d_t_off,
+                                                                          total_nq, d_part);
+    if ((e = hipGetLastError()) != hipSuccess)
+        return e;
+    if (events && (e = hipEventRecord(events[1], stream)) != hipSuccess)
+        return e;
+    knn_merge_frames_kernel<<<dim3((unsigned)p.q_blocks, (unsigned)n_frames), 256, 0, stream>>>(
+        d_part, d_q_off, d_t_off, total_nq, p.n_splits, p.waves, k, d_out_idx, d_out_dist, d_keep,
+        ratio);
+    if ((e = hipGetLastError()) != hipSuccess)
+        return e;
+    if (events && (e = hipEventRecord(events[2], stream)) != hipSuccess)
+        return e;
     if (events && (e = hipEventRecord(events[3], stream)) != hipSuccess)
         return e;
     return hipSuccess;

@@ -119,6 +119,19 @@ struct Context {
     DevBuf d_in;            // host entry points: device copy of the gathered inputs
     PinBuf h_in, h_out;     // host entry points: pinned gather buffer / zero-copy results
     DevBuf pnp_idx;         // RANSAC-EPnP: inlier rows of the refit
+    // Frame-offset tables of batched calls travel through a small ring of pinned
+    // slots (one asynchronous copy each; a slot is reused once its call has finished).
+    struct OffsetSlot {
+        PinBuf h;
+        DevBuf d;
+        hipEvent_t done = nullptr;
+    };
+    OffsetSlot off_ring[4];
+    int off_next = 0;
+    // The workspace above is shared by all calls: the stream that used it last.
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
+    hipEvent_t scratch_ev = nullptr;
     bool profiling = false;                 // record events around the distance kernel
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -148,6 +161,28 @@ ph_status check_rows(const void *p, int64_t n, const char *what)
     if (n > 0x7FFFFFFF)
         return fail(PH_ERR_TOO_LARGE, "%s: %lld rows exceed the 32-bit index range", what,
                     (long long)n);
+    return PH_OK;
+}
+
+// Work queued on another stream may still be using the shared workspace: make `st`
+// wait for it (same stream: stream order already does).
+ph_status scratch_guard(hipStream_t st)
+{
+    if (g_ctx.scratch_used && g_ctx.scratch_stream != st) {
+        hipError_t e = hipSuccess;
+        if (!g_ctx.scratch_ev)
+            e = hipEventCreateWithFlags(&g_ctx.scratch_ev, hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipEventRecord(g_ctx.scratch_ev, g_ctx.scratch_stream);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(st, g_ctx.scratch_ev, 0);
+        if (e != hipSuccess) { // e.g. the caller destroyed the earlier stream
+            (void)hipGetLastError();
+            PH_HIP(hipDeviceSynchronize());
+        }
+    }
+    g_ctx.scratch_stream = st;
+    g_ctx.scratch_used = true;
     return PH_OK;
 }
 
@@ -185,6 +220,9 @@ ph_status knn_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t n
     KnnPlan plan = knn_plan(nq, nt, g_ctx.n_cus);
     if (plan.rows_per_split * (int64_t)plan.n_splits < nt)
         return fail(PH_ERR_TOO_LARGE, "train set of %lld rows is too large for one call", (long long)nt);
+    ph_status gs = scratch_guard(st);
+    if (gs != PH_OK)
+        return gs;
     PH_HIP(part.reserve(plan.part_bytes));
     hipEvent_t *ev = g_ctx.profiling ? g_ctx.ev : nullptr;
     PH_HIP(knn_launch(plan, d_q, nq, d_t, nt, k, base, (uint32_t *)part.p, d_idx, d_dist, d_keep,
@@ -204,6 +242,9 @@ ph_status crosscheck_dev_locked(const void *d_q, int64_t nq, const void *d_t, in
         PH_HIP(hipGetLastError());
         return PH_OK;
     }
+    ph_status gs = scratch_guard(st);
+    if (gs != PH_OK)
+        return gs;
     PH_HIP(g_ctx.tmp_i.reserve((size_t)nt * sizeof(int32_t)));
     PH_HIP(g_ctx.tmp_d.reserve((size_t)nt * sizeof(int32_t)));
     PH_HIP(g_ctx.best.reserve((size_t)nq * sizeof(unsigned long long)));
@@ -401,13 +442,21 @@ void ph_shutdown(void)
     if (!g_ctx.ready)
         return;
     (void)hipSetDevice(g_ctx.device);
-    (void)hipStreamSynchronize(g_ctx.stream);
+    (void)hipDeviceSynchronize(); // callers' streams may still hold work that uses the workspace
     DevBuf *all[] = {&g_ctx.part,  &g_ctx.part2, &g_ctx.best,   &g_ctx.tmp_i,
                      &g_ctx.tmp_d, &g_ctx.d_in,  &g_ctx.pnp_idx};
     for (DevBuf *b : all)
         b->release();
     g_ctx.h_in.release();
     g_ctx.h_out.release();
+    for (Context::OffsetSlot &slot : g_ctx.off_ring) {
+        slot.h.release();
+        slot.d.release();
+        if (slot.done)
+            (void)hipEventDestroy(slot.done);
+    }
+    if (g_ctx.scratch_ev)
+        (void)hipEventDestroy(g_ctx.scratch_ev);
     (void)hipStreamDestroy(g_ctx.stream);
     for (hipEvent_t e : g_ctx.ev)
         if (e)
@@ -508,6 +557,83 @@ ph_status ph_knn_hamming256_dev(const void *d_query, int64_t nq, const void *d_t
         return fail(PH_ERR_INVALID_ARG, "null output pointer");
     return knn_dev_locked(d_query, nq, d_train, nt, k, train_index_base, d_out_idx, d_out_dist,
                           d_keep, ratio, g_ctx.part, pick_stream(stream));
+}
+
+ph_status ph_knn_hamming256_frames_dev(const void *d_query, const int32_t *q_offsets,
+                                       const void *d_train, const int32_t *t_offsets,
+                                       int n_frames, int k, int32_t *d_out_idx,
+                                       int32_t *d_out_dist, uint8_t *d_keep, float ratio,
+                                       void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (k != 1 && k != 2)
+        return fail(PH_ERR_INVALID_ARG, "k must be 1 or 2 (got %d)", k);
+    if (d_keep && k != 2)
+        return fail(PH_ERR_INVALID_ARG, "the ratio test needs k == 2");
+    if (n_frames < 0 || n_frames > 65535)
+        return fail(PH_ERR_INVALID_ARG, "n_frames must be in 0..65535 (got %d)", n_frames);
+    if (n_frames == 0)
+        return PH_OK;
+    if (!q_offsets || !t_offsets)
+        return fail(PH_ERR_INVALID_ARG, "null offset table");
+    if (q_offsets[0] < 0 || t_offsets[0] < 0)
+        return fail(PH_ERR_INVALID_ARG, "negative offset");
+    int64_t max_nq = 0, max_nt = 0;
+    for (int f = 0; f < n_frames; f++) {
+        const int64_t a = (int64_t)q_offsets[f + 1] - q_offsets[f];
+        const int64_t b = (int64_t)t_offsets[f + 1] - t_offsets[f];
+        if (a < 0 || b < 0)
+            return fail(PH_ERR_INVALID_ARG, "offsets of frame %d are not ascending", f);
+        max_nq = std::max(max_nq, a);
+        max_nt = std::max(max_nt, b);
+    }
+    const int64_t row_begin = q_offsets[0], row_end = q_offsets[n_frames];
+    if (row_end == row_begin)
+        return PH_OK;
+    if (!d_query || !d_out_idx || !d_out_dist || (max_nt > 0 && !d_train))
+        return fail(PH_ERR_INVALID_ARG, "null pointer");
+    hipStream_t st = pick_stream(stream);
+    if (max_nt == 0) {
+        const int64_t rows = row_end - row_begin;
+        fill_empty_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, st>>>(
+            d_out_idx + row_begin * k, d_out_dist + row_begin * k,
+            d_keep ? d_keep + row_begin : nullptr, rows, k);
+        PH_HIP(hipGetLastError());
+        return PH_OK;
+    }
+    if (((uintptr_t)d_query & 15) || ((uintptr_t)d_train & 15))
+        return fail(PH_ERR_INVALID_ARG, "descriptor buffers must be 16-byte aligned");
+    const KnnPlan plan = knn_plan_frames(n_frames, max_nq, max_nt, row_end, g_ctx.n_cus);
+    if (frame_rows_per_split(max_nt, plan) * (int64_t)plan.n_splits < max_nt)
+        return fail(PH_ERR_TOO_LARGE, "train set of %lld rows is too large for one call",
+                    (long long)max_nt);
+    if ((s = scratch_guard(st)) != PH_OK)
+        return s;
+    PH_HIP(g_ctx.part.reserve(plan.part_bytes));
+    // offsets: host -> pinned slot -> device, in stream order
+    Context::OffsetSlot &slot = g_ctx.off_ring[g_ctx.off_next];
+    g_ctx.off_next = (g_ctx.off_next + 1) % 4;
+    if (!slot.done)
+        PH_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    else
+        PH_HIP(hipEventSynchronize(slot.done));
+    const size_t tab = (size_t)(n_frames + 1) * sizeof(int32_t);
+    PH_HIP(slot.h.reserve(2 * tab));
+    PH_HIP(slot.d.reserve(2 * tab));
+    memcpy(slot.h.p, q_offsets, tab);
+    memcpy((uint8_t *)slot.h.p + tab, t_offsets, tab);
+    PH_HIP(hipMemcpyAsync(slot.d.p, slot.h.p, 2 * tab, hipMemcpyHostToDevice, st));
+    const int32_t *d_q_off = (const int32_t *)slot.d.p, *d_t_off = d_q_off + (n_frames + 1);
+    hipEvent_t *ev = g_ctx.profiling ? g_ctx.ev : nullptr;
+    PH_HIP(knn_frames_launch(plan, d_query, d_q_off, d_train, d_t_off, n_frames, row_end, k,
+                             (uint32_t *)g_ctx.part.p, d_out_idx, d_out_dist, d_keep, ratio, st,
+                             ev));
+    PH_HIP(hipEventRecord(slot.done, st));
+    g_ctx.ev_valid = ev != nullptr;
+    return PH_OK;
 }
 
 ph_status ph_knn_merge_dev(const int32_t *d_cand_idx, const int32_t *d_cand_dist, int n_shards,

@@ -94,3 +94,39 @@ def knn_train_sharded(d_query, d_train_shard, shard_base, k, ratio=None, group=N
                                     keep.data_ptr() if keep is not None else None,
                                     float(ratio) if ratio is not None else 0.0, sp))
     return out_idx, out_dst, keep
+
+
+def knn_frames(d_query, q_offsets, d_train, t_offsets, k, ratio=None):
+    """k-NN of a batch of independent frames in one launch (this rank's block of a
+    frame-sharded job): frame f matches query rows [q_offsets[f], q_offsets[f+1]) of
+    d_query against train rows [t_offsets[f], t_offsets[f+1]) of d_train.
+
+    d_query / d_train: uint8 [rows, 32] GPU tensors (may be the same tensor);
+    q_offsets / t_offsets: host sequences of n_frames + 1 ascending ints.
+    Returns (idx [rows, k], dist [rows, k], keep [rows] or None) indexed by query
+    row of d_query; train indices are relative to the frame's first train row.
+    Rows outside [q_offsets[0], q_offsets[-1]) are left as (-1, INT_MAX, 0).
+    """
+    import numpy as np
+    lib = _lib.load()
+    qo = np.ascontiguousarray(q_offsets, dtype=np.int32)
+    to = np.ascontiguousarray(t_offsets, dtype=np.int32)
+    if qo.ndim != 1 or qo.shape != to.shape or qo.size < 1:
+        raise ValueError("q_offsets and t_offsets must be 1-D and of equal length >= 1")
+    if qo.size > 1 and (int(qo[-1]) > d_query.shape[0] or int(to[-1]) > d_train.shape[0]):
+        raise ValueError("offsets exceed the descriptor buffers")
+    sp = _stream_ptr()
+    if sp is None:
+        raise RuntimeError("run under `with torch.cuda.stream(torch.cuda.Stream())`: torch's "
+                           "default stream has no handle to pass through the C ABI")
+    rows, dev = d_query.shape[0], d_query.device
+    idx = torch.full((rows, k), -1, dtype=torch.int32, device=dev)
+    dst = torch.full((rows, k), 2147483647, dtype=torch.int32, device=dev)
+    keep = torch.zeros(rows, dtype=torch.uint8, device=dev) if ratio is not None else None
+    i32p = C.POINTER(C.c_int32)
+    _lib.check(lib.ph_knn_hamming256_frames_dev(
+        d_query.data_ptr(), qo.ctypes.data_as(i32p), d_train.data_ptr(), to.ctypes.data_as(i32p),
+        qo.size - 1, k, idx.data_ptr(), dst.data_ptr(),
+        keep.data_ptr() if keep is not None else None,
+        float(ratio) if ratio is not None else 0.0, sp))
+    return idx, dst, keep

@@ -397,3 +397,125 @@ def test_shutdown_and_reinit(posehip):
     posehip.init(0)
     idx, dist = gpu_knn(posehip, q, q, 1)
     assert (idx[:, 0] == np.arange(100)).all() and (dist == 0).all()
+
+
+# ---- batches of frames in one launch --------------------------------------------
+def _frames_reference(q, qo, t, to, k):
+    idx = np.full((q.shape[0], k), -1, np.int32)
+    dist = np.full((q.shape[0], k), INT_MAX, np.int32)
+    for f in range(len(qo) - 1):
+        if qo[f + 1] > qo[f]:
+            i, d = orc.knn(q[qo[f]:qo[f + 1]], t[to[f]:to[f + 1]], k)
+            idx[qo[f]:qo[f + 1]], dist[qo[f]:qo[f + 1]] = i, d
+    return idx, dist
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_frames_ragged(posehip, k):
+    """Ragged frames in one launch, each checked against the oracle run per frame:
+    an empty frame, a frame without train rows, one train row with k = 2, sizes
+    around the 64-query block and the 4-row group, odd train offsets."""
+    import torch
+    from poseestimation_amd import distributed as D
+    nqs = [500, 0, 64, 65, 1, 300, 777, 129]
+    nts = [431, 50, 1, 3, 1000, 0, 2051, 64]
+    qo, to = np.concatenate([[0], np.cumsum(nqs)]), np.concatenate([[0], np.cumsum(nts)])
+    q = datagen.codebook_descriptors(int(qo[-1]), 41, words=256)   # many equal distances
+    t = datagen.codebook_descriptors(int(to[-1]), 42, words=256)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        idx, dist, keep = D.knn_frames(_dev(q), qo, _dev(t), to, k, ratio=0.8 if k == 2 else None)
+        torch.cuda.current_stream().synchronize()
+    ridx, rdist = _frames_reference(q, qo, t, to, k)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(dist.cpu().numpy(), rdist)
+    if k == 2:
+        want = (ridx[:, 1] >= 0) & (rdist[:, 0].astype(np.float32)
+                                    < np.float32(0.8) * rdist[:, 1].astype(np.float32))
+        assert np.array_equal(keep.cpu().numpy().astype(bool), want)
+
+
+def test_frames_video_stream(posehip):
+    """Frame f against frame f-1 of ONE descriptor buffer (what the reference's loop
+    does with descriptors / descriptorsOld, src/cereal_box.cpp:341-344), and a window
+    that does not start at row 0."""
+    import torch
+    from poseestimation_amd import distributed as D
+    counts = [500, 480, 500, 499, 350, 500]
+    off = np.concatenate([[0], np.cumsum(counts)])
+    base = datagen.random_descriptors(500, 43)
+    frames = [datagen.perturbed_copy(base, 44 + f, max_flips=30)[:c]
+              for f, c in enumerate(counts)]
+    buf = np.concatenate(frames)
+    d_buf = _dev(buf)
+    qo, to = off[1:], off[:-1]      # frames 1..5 query, frames 0..4 train
+    with torch.cuda.stream(torch.cuda.Stream()):
+        idx, dist, _ = D.knn_frames(d_buf, qo, d_buf, to, 2)
+        torch.cuda.current_stream().synchronize()
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert (idx[:off[1]] == -1).all() and (dist[:off[1]] == INT_MAX).all()   # frame 0: untouched
+    for f in range(1, len(counts)):
+        ri, rd = orc.knn(frames[f], frames[f - 1], 2)
+        assert np.array_equal(idx[off[f]:off[f + 1]], ri)
+        assert np.array_equal(dist[off[f]:off[f + 1]], rd)
+
+
+def test_frames_equal_single_calls_at_bench_shape(posehip):
+    """Four 10k x 10k frames in one launch == four single-frame calls (bit for bit)."""
+    import torch
+    from poseestimation_amd import distributed as D
+    n, F = 10000, 4
+    q = datagen.random_descriptors(n * F, 51)
+    t = datagen.random_descriptors(n * F, 52)
+    d_q, d_t = _dev(q), _dev(t)
+    off = np.arange(F + 1) * n
+    with torch.cuda.stream(torch.cuda.Stream()):
+        idx, dist, keep = D.knn_frames(d_q, off, d_t, off, 2, ratio=0.75)
+        torch.cuda.current_stream().synchronize()
+    for f in range(F):
+        i1, d1, k1 = gpu_knn_dev(posehip, d_q[f * n:(f + 1) * n], d_t[f * n:(f + 1) * n], 2,
+                                 ratio=0.75)
+        assert torch.equal(idx[f * n:(f + 1) * n], i1) and torch.equal(dist[f * n:(f + 1) * n], d1)
+        assert torch.equal(keep[f * n:(f + 1) * n], k1)
+
+
+def test_frames_invalid_arguments(posehip):
+    lib = posehip.load()
+    i32 = C.POINTER(C.c_int32)
+    bad = np.array([0, 10, 5], np.int32)
+    ok = np.array([0, 10, 20], np.int32)
+    st = lib.ph_knn_hamming256_frames_dev(1 << 12, bad.ctypes.data_as(i32), 1 << 12,
+                                          ok.ctypes.data_as(i32), 2, 2, 1 << 12, 1 << 12, None,
+                                          0.0, None)
+    assert st == 1 and b"ascending" in lib.ph_last_error_string()
+    st = lib.ph_knn_hamming256_frames_dev(1 << 12, ok.ctypes.data_as(i32), 1 << 12,
+                                          ok.ctypes.data_as(i32), 2, 3, 1 << 12, 1 << 12, None,
+                                          0.0, None)
+    assert st == 1
+    st = lib.ph_knn_hamming256_frames_dev(None, None, None, None, 0, 2, None, None, None, 0.0,
+                                          None)
+    assert st == 0   # no frames: nothing to do
+
+
+def test_calls_on_two_streams_are_ordered(posehip):
+    """The workspace is shared, so a call on another stream must wait for the
+    previous one: alternate two streams without any host synchronisation between."""
+    import torch
+    lib = posehip.load()
+    qs = [datagen.random_descriptors(3000, 60 + i) for i in range(6)]
+    t = datagen.random_descriptors(5000, 70)
+    d_t = _dev(t)
+    d_qs = [_dev(x) for x in qs]
+    outs = [(torch.empty((3000, 2), dtype=torch.int32, device="cuda:0"),
+             torch.empty((3000, 2), dtype=torch.int32, device="cuda:0")) for _ in qs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for i, d_q in enumerate(d_qs):
+        sp = C.c_void_p(streams[i % 2].cuda_stream)
+        posehip.check(lib.ph_knn_hamming256_dev(d_q.data_ptr(), 3000, d_t.data_ptr(), 5000, 2, 0,
+                                                outs[i][0].data_ptr(), outs[i][1].data_ptr(),
+                                                None, 0.0, sp))
+    torch.cuda.synchronize()
+    for i, x in enumerate(qs):
+        ri, rd = orc.knn(x, t, 2, threads=8)
+        assert np.array_equal(outs[i][0].cpu().numpy(), ri)
+        assert np.array_equal(outs[i][1].cpu().numpy(), rd)

@@ -19,6 +19,35 @@ int main(int argc, char **argv)
     if (argc == 3) sizes = {{atol(argv[1]), atol(argv[2]), 10}};
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (argc == 4) { // nq nt F: F independent nq x nt frames in ONE batched launch
+        const long nq = atol(argv[1]), nt = atol(argv[2]); const int F = atoi(argv[3]);
+        std::mt19937_64 rng(7);
+        std::vector<uint64_t> hq(nq * F * 4), ht(nt * F * 4);
+        for (auto &v : hq) v = rng();
+        for (auto &v : ht) v = rng();
+        std::vector<int32_t> qo(F + 1), to(F + 1);
+        for (int f = 0; f <= F; f++) { qo[f] = (int32_t)(f * nq); to[f] = (int32_t)(f * nt); }
+        void *dq, *dt; int32_t *di, *dd; uint8_t *dk;
+        CK(hipMalloc(&dq, hq.size() * 8)); CK(hipMalloc(&dt, ht.size() * 8));
+        CK(hipMalloc(&di, nq * F * 8)); CK(hipMalloc(&dd, nq * F * 8)); CK(hipMalloc(&dk, nq * F));
+        CK(hipMemcpy(dq, hq.data(), hq.size() * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dt, ht.data(), ht.size() * 8, hipMemcpyHostToDevice));
+        for (int w = 0; w < 3; w++) PH(ph_knn_hamming256_frames_dev(dq, qo.data(), dt, to.data(), F, 2, di, dd, dk, 0.75f, st));
+        CK(hipStreamSynchronize(st));
+        std::vector<float> ts;
+        for (int r = 0; r < 10; r++) {
+            CK(hipEventRecord(e0, st));
+            PH(ph_knn_hamming256_frames_dev(dq, qo.data(), dt, to.data(), F, 2, di, dd, dk, 0.75f, st));
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
+        }
+        std::sort(ts.begin(), ts.end());
+        printf("{\"frames\": %d, \"nq\": %ld, \"nt\": %ld, \"ms_median\": %.4f, \"ms_min\": %.4f, \"evals_per_s_median\": %.4g}\n",
+               F, nq, nt, ts[ts.size() / 2], ts[0], (double)F * nq * nt / (ts[ts.size() / 2] * 1e-3));
+        ph_shutdown();
+        return 0;
+    }
     for (auto s : sizes) {
         std::mt19937_64 rng(7);
         std::vector<uint64_t> hq(s.nq * 4), ht(s.nt * 4);
