@@ -122,6 +122,28 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
                    "n_hyp": H, "n_points": n, "problems_per_step": P},
         "dtype": "f64 solve, f32 reprojection error",
     }
+    if rank == 0:
+        # whole solvePnPRansac calls (sampling, adaptive budget, inlier mask, refit) from host
+        # buffers: a batch of frames of the reference's size in ONE call, and one frame per call
+        import poseestimation_amd as pa
+        fr = [datagen.pnp_scene(n=500, outlier_frac=0.3, seed=500 + f) for f in range(256)]
+        fo, fi = [f[0] for f in fr], [f[1] for f in fr]
+        pa.solvePnPRansacBatch(fo, fi, datagen.CAMERA_K, None, iterationsCount=100)
+        c0 = time.perf_counter()
+        for _ in range(5):
+            pa.solvePnPRansacBatch(fo, fi, datagen.CAMERA_K, None, iterationsCount=100)
+        tb = (time.perf_counter() - c0) / 5
+        pa.solvePnPRansac(fo[0], fi[0], datagen.CAMERA_K, None, iterationsCount=100)
+        c0 = time.perf_counter()
+        for f in range(16):
+            pa.solvePnPRansac(fo[f], fi[f], datagen.CAMERA_K, None, iterationsCount=100)
+        t1 = (time.perf_counter() - c0) / 16
+        res["solvepnp_ransac_host_calls"] = {
+            "workload": "256 frames x 500 correspondences, 30% outliers, iterationsCount 100 "
+                        "(BASELINE configs[0] size), host buffers, PCIe and host replay included",
+            "batched_poses_per_s": 256 / tb, "batched_call_ms": tb * 1e3,
+            "single_call_ms": t1 * 1e3,
+        }
     if rank == 0 and not args.no_cpu_baseline:
         import oracle_bind as orc
         try:

@@ -90,6 +90,13 @@ int main()
     const bool ok = solvePnPRansac(obj, img, K, rvec, tvec, false, 100, 8.0f, 0.99, &inliers);
     std::printf("pnp ok %d inliers %zu rvec %.6f %.6f %.6f tvec %.6f %.6f %.6f\n", (int)ok, inliers.size(), rvec[0],
                 rvec[1], rvec[2], tvec[0], tvec[1], tvec[2]);
+    // the same frame three times as one batched call: every result equals the single call
+    const std::vector<PnPResult> batch = solvePnPRansacBatch({obj, obj, obj}, {img, img, img}, K);
+    bool same = batch.size() == 3;
+    for (const PnPResult &r : batch)
+        same = same && r.found && r.inliers == inliers && std::memcmp(r.rvec, rvec, sizeof(rvec)) == 0 &&
+               std::memcmp(r.tvec, tvec, sizeof(tvec)) == 0;
+    std::printf("pnp batch of 3 identical to the single call: %d\n", (int)same);
     ph_shutdown();
-    return ok && inliers.size() >= 300 && inliers.size() <= 305 ? 0 : 1;
+    return ok && same && inliers.size() >= 300 && inliers.size() <= 305 ? 0 : 1;
 }

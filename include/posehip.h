@@ -170,6 +170,26 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
                                   int32_t *inliers, int *n_inliers, int *found,
                                   int *iterations_run);
 
+/* The call above for a batch of independent problems (one per frame) that share K
+ * and the RANSAC parameters: problem p owns rows [point_offsets[p],
+ * point_offsets[p+1]) of obj / img (n_problems + 1 ascending host offsets) and gets
+ * exactly the result a separate ph_solvepnp_ransac_epnp call on its rows would
+ * give (the sampler restarts from rng_state for every problem, as OpenCV
+ * constructs its RNG inside every call).  The hypotheses of all problems are
+ * solved and scored together, a GPU-full at a time, so a batch costs about the
+ * latency of one call.  rvecs / tvecs: 3 doubles per problem; found,
+ * n_inliers (may be NULL), iterations_run (may be NULL): one int32 per problem;
+ * inliers (may be NULL): as many entries as rows, problem p's ascending,
+ * problem-relative inlier rows start at inliers[point_offsets[p]].  A problem
+ * with fewer than 5 rows gets found = 0 (where the single call reports an
+ * error).  No counterpart in the reference, which solves one frame at a time. */
+ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
+                                          const int32_t *point_offsets, int n_problems,
+                                          const double *K, int iterations_count, float reproj_err,
+                                          double confidence, uint64_t rng_state, double *rvecs,
+                                          double *tvecs, int32_t *inliers, int32_t *n_inliers,
+                                          int32_t *found, int32_t *iterations_run);
+
 /* cv::solvePnP(obj, img, K, noArray(), rvec, tvec, false, SOLVEPNP_EPNP) on
  * n >= 4 correspondences (the per-sample kernel and the final refit of the call
  * above). */

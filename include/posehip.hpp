@@ -211,6 +211,63 @@ inline bool solvePnPRansac(const std::vector<Point3f> &objectPoints, const std::
     return found != 0;
 }
 
+// solvePnPRansac for a batch of frames in one call (shared camera and RANSAC
+// parameters); element p of the result is what solvePnPRansac on frame p returns.
+struct PnPResult {
+    bool found = false;
+    double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};
+    std::vector<int> inliers;
+    int iterations = 0;
+};
+
+inline std::vector<PnPResult> solvePnPRansacBatch(const std::vector<std::vector<Point3f>> &objectPoints,
+                                                  const std::vector<std::vector<Point2f>> &imagePoints,
+                                                  const double cameraMatrix[9], int iterationsCount = 100,
+                                                  float reprojectionError = 8.0f, double confidence = 0.99)
+{
+    if (objectPoints.size() != imagePoints.size())
+        throw Error(PH_ERR_INVALID_ARG, "objectPoints and imagePoints differ in length");
+    if (ph_device() < 0)
+        check(ph_init(0));
+    const int P = (int)objectPoints.size();
+    std::vector<PnPResult> out((std::size_t)P);
+    if (P == 0)
+        return out;
+    std::vector<std::int32_t> off((std::size_t)P + 1, 0);
+    for (int p = 0; p < P; p++) {
+        if (objectPoints[p].size() != imagePoints[p].size())
+            throw Error(PH_ERR_INVALID_ARG, "objectPoints and imagePoints of a frame differ in length");
+        off[p + 1] = off[p] + (std::int32_t)objectPoints[p].size();
+    }
+    std::vector<Point3f> obj;
+    std::vector<Point2f> img;
+    obj.reserve((std::size_t)off[P] + 1);
+    img.reserve((std::size_t)off[P] + 1);
+    for (int p = 0; p < P; p++) {
+        obj.insert(obj.end(), objectPoints[p].begin(), objectPoints[p].end());
+        img.insert(img.end(), imagePoints[p].begin(), imagePoints[p].end());
+    }
+    if (obj.empty()) { // keep the pointers valid
+        obj.push_back({0, 0, 0});
+        img.push_back({0, 0});
+    }
+    std::vector<double> rv((std::size_t)P * 3), tv((std::size_t)P * 3);
+    std::vector<std::int32_t> inl(obj.size()), n_inl((std::size_t)P), found((std::size_t)P), iters((std::size_t)P);
+    check(ph_solvepnp_ransac_epnp_batched(&obj[0].x, &img[0].x, off.data(), P, cameraMatrix, iterationsCount,
+                                          reprojectionError, confidence, 0xFFFFFFFFFFFFFFFFull, rv.data(),
+                                          tv.data(), inl.data(), n_inl.data(), found.data(), iters.data()));
+    for (int p = 0; p < P; p++) {
+        PnPResult &r = out[(std::size_t)p];
+        r.found = found[p] != 0;
+        r.iterations = iters[p];
+        std::memcpy(r.rvec, &rv[(std::size_t)p * 3], sizeof(r.rvec));
+        std::memcpy(r.tvec, &tv[(std::size_t)p * 3], sizeof(r.tvec));
+        if (r.found)
+            r.inliers.assign(inl.begin() + off[p], inl.begin() + off[p] + n_inl[p]);
+    }
+    return out;
+}
+
 #ifdef POSEHIP_WITH_OPENCV
 // Drop-in overloads on OpenCV's own types.
 inline void match(const BFMatcher &m, const cv::Mat &query, const cv::Mat &train, std::vector<cv::DMatch> &out)

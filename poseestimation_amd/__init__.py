@@ -6,7 +6,7 @@ interfaces the reference calls on that path.
 """
 from . import _lib
 from .matcher import NORM_HAMMING, BFMatcher, DMatch, min_dist_filter, ratio_test_match
-from .pnp import SOLVEPNP_EPNP, solvePnP, solvePnPRansac
+from .pnp import SOLVEPNP_EPNP, solvePnP, solvePnPRansac, solvePnPRansacBatch
 
 __all__ = ["_lib", "NORM_HAMMING", "BFMatcher", "DMatch", "min_dist_filter", "ratio_test_match",
-           "SOLVEPNP_EPNP", "solvePnP", "solvePnPRansac"]
+           "SOLVEPNP_EPNP", "solvePnP", "solvePnPRansac", "solvePnPRansacBatch"]

@@ -61,6 +61,9 @@ SIGNATURES = {
     "ph_solvepnp_ransac_epnp": (C.c_int, [_f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_float,
                                           C.c_double, C.c_uint64, _f64p, _f64p, _i32p, _intp,
                                           _intp, _intp]),
+    "ph_solvepnp_ransac_epnp_batched": (C.c_int, [_f32p, _f32p, _i32p, C.c_int, _f64p, C.c_int,
+                                                  C.c_float, C.c_double, C.c_uint64, _f64p, _f64p,
+                                                  _i32p, _i32p, _i32p, _i32p]),
     "ph_solvepnp_epnp": (C.c_int, [_f32p, _f32p, C.c_int, _f64p, _f64p, _f64p]),
     "ph_ransac_epnp_hypotheses_batched_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                         _f64p, C.c_void_p, C.c_int, C.c_float,

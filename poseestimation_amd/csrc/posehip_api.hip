@@ -358,9 +358,8 @@ struct CvRng {
 // accepts): five distinct row indices, redrawing a slot while it repeats an
 // earlier one.  The draws do not depend on any model, so the whole sequence of
 // subsets can be generated before a single hypothesis is solved.
-void draw_subsets(uint64_t rng_state, int count, int n_subsets, int32_t *out)
+void draw_subsets(CvRng &rng, int count, int n_subsets, int32_t *out)
 {
-    CvRng rng(rng_state);
     for (int s = 0; s < n_subsets; s++) {
         int32_t *idx = out + (size_t)s * 5;
         for (int i = 0; i < 5; i++) {
@@ -375,6 +374,12 @@ void draw_subsets(uint64_t rng_state, int count, int n_subsets, int32_t *out)
             idx[i] = v;
         }
     }
+}
+
+void draw_subsets(uint64_t rng_state, int count, int n_subsets, int32_t *out)
+{
+    CvRng rng(rng_state);
+    draw_subsets(rng, count, n_subsets, out);
 }
 
 // RANSACUpdateNumIters.
@@ -783,8 +788,8 @@ ph_status ph_ransac_epnp_hypotheses_dev(const float *d_obj, const float *d_img, 
     if (n < 5 || n_hyp < 0 || (n_hyp > 0 && (!d_subsets || !d_models || !d_counts)))
         return fail(PH_ERR_INVALID_ARG, "need >= 5 correspondences and non-null buffers");
     const double thr = reproj_err;
-    PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, camera_of(K), d_subsets, nullptr, 1, n_hyp,
-                                    (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
+    PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, camera_of(K), d_subsets, nullptr, nullptr, 1,
+                                    n_hyp, (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
                                     pick_stream(stream)));
     return PH_OK;
 }
@@ -811,8 +816,9 @@ ph_status ph_ransac_epnp_hypotheses_batched_dev(const float *d_obj, const float 
         return fail(PH_ERR_INVALID_ARG, "null pointer");
     const double thr = reproj_err;
     PH_HIP(ransac_hypotheses_launch(d_obj, d_img, 0, camera_of(K), d_subsets, d_point_offsets,
-                                    n_problems, hyp_per_problem, (float)(thr * thr), d_models,
-                                    d_counts, g_ctx.n_cus, pick_stream(stream)));
+                                    d_point_offsets + 1, n_problems, hyp_per_problem,
+                                    (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
+                                    pick_stream(stream)));
     return PH_OK;
 }
 
@@ -945,8 +951,8 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
     for (int base = 0; base < total && base < niters; base += chunk) {
         const int m = std::min(chunk, total - base);
         PH_HIP(ransac_hypotheses_launch(d.obj, d.img, n, cam, d.subsets + (size_t)base * 5, nullptr,
-                                        1, m, thr2, (double *)db, (int32_t *)(db + counts_off),
-                                        g_ctx.n_cus, st));
+                                        nullptr, 1, m, thr2, (double *)db,
+                                        (int32_t *)(db + counts_off), g_ctx.n_cus, st));
         PH_HIP(hipStreamSynchronize(st));
         for (iter = base; iter < base + m && iter < niters; iter++) {
             const int good = counts[iter - base];
@@ -1000,6 +1006,224 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
     if (n_inliers)
         *n_inliers = k;
     *found = 1;
+    return PH_OK;
+}
+
+ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
+                                          const int32_t *point_offsets, int n_problems,
+                                          const double *K, int iterations_count, float reproj_err,
+                                          double confidence, uint64_t rng_state, double *rvecs,
+                                          double *tvecs, int32_t *inliers, int32_t *n_inliers,
+                                          int32_t *found, int32_t *iterations_run)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (n_problems < 0 || n_problems > 65535)
+        return fail(PH_ERR_INVALID_ARG, "n_problems must be in 0..65535 (got %d)", n_problems);
+    if (n_problems == 0)
+        return PH_OK;
+    if (!point_offsets || !rvecs || !tvecs || !found)
+        return fail(PH_ERR_INVALID_ARG, "point_offsets, rvecs, tvecs and found must be non-null");
+    if (point_offsets[0] < 0)
+        return fail(PH_ERR_INVALID_ARG, "negative offset");
+    int max_n = 0;
+    for (int p = 0; p < n_problems; p++) {
+        const int64_t c = (int64_t)point_offsets[p + 1] - point_offsets[p];
+        if (c < 0)
+            return fail(PH_ERR_INVALID_ARG, "offsets of problem %d are not ascending", p);
+        max_n = std::max(max_n, (int)c);
+    }
+    const int row_lo = point_offsets[0], row_hi = point_offsets[n_problems];
+    if ((s = check_pnp_args(obj, img, row_hi, K)) != PH_OK)
+        return s;
+    if (!(confidence > 0 && confidence < 1))
+        return fail(PH_ERR_INVALID_ARG, "confidence must lie in (0, 1)");
+    for (int p = 0; p < n_problems; p++) {
+        found[p] = 0;
+        if (n_inliers)
+            n_inliers[p] = 0;
+        if (iterations_run)
+            iterations_run[p] = 0;
+    }
+    const int model_points = 5;
+    const CameraK cam = camera_of(K);
+    const double thr = reproj_err;
+    const float thr2 = (float)(thr * thr);
+    hipStream_t st = g_ctx.stream;
+
+    struct Prob {
+        CvRng rng;
+        int n, niters, iter = 0, max_good = 0;
+        double best[6] = {0, 0, 0, 0, 0, 0};
+        bool live;
+    };
+    std::vector<Prob> pr;
+    pr.reserve((size_t)n_problems);
+    for (int p = 0; p < n_problems; p++) {
+        Prob q{CvRng(rng_state)};
+        q.n = point_offsets[p + 1] - point_offsets[p];
+        q.niters = std::max(iterations_count, 1);
+        q.live = q.n > model_points; // fewer: no pose; exactly five: one solve, no sampling
+        pr.push_back(q);
+    }
+
+    // Hypotheses per round: enough to fill the GPU, shared by the live problems.
+    const int hyp_target = g_ctx.n_cus * 96;
+    const size_t cap_hyps = (size_t)std::max(hyp_target, n_problems * 32);
+    // pinned input area: obj | img staging, then small tables the kernels read in place
+    const size_t rows = (size_t)row_hi;
+    const size_t img_off = align256(rows * 12), tab_off = img_off + align256(rows * 8);
+    const size_t np4 = align256((size_t)n_problems * sizeof(int32_t));
+    const size_t beg_off = tab_off, end_off = beg_off + np4, rowb_off = end_off + np4;
+    const size_t ibeg_off = rowb_off + np4, icnt_off = ibeg_off + np4;
+    const size_t best_off = icnt_off + np4;
+    const size_t sub_off = best_off + align256((size_t)n_problems * 6 * sizeof(double));
+    const size_t idx_off = sub_off + align256(cap_hyps * 5 * sizeof(int32_t));
+    const size_t in_total = idx_off + align256(rows * sizeof(int32_t));
+    PH_HIP(g_ctx.h_in.reserve(in_total));
+    PH_HIP(g_ctx.d_in.reserve(tab_off));
+    uint8_t *hi = (uint8_t *)g_ctx.h_in.p, *di = (uint8_t *)g_ctx.h_in.dp;
+    memcpy(hi, obj, rows * 12);
+    memcpy(hi + img_off, img, rows * 8);
+    PH_HIP(hipMemcpyAsync(g_ctx.d_in.p, hi, tab_off, hipMemcpyHostToDevice, st));
+    const float *d_obj = (const float *)g_ctx.d_in.p;
+    const float *d_img = (const float *)((const uint8_t *)g_ctx.d_in.p + img_off);
+    // pinned result area, written by the kernels: models | counts | mask | refit models
+    const size_t cnt_off = align256(cap_hyps * 6 * sizeof(double));
+    const size_t mask_off = cnt_off + align256(cap_hyps * sizeof(int32_t));
+    const size_t refit_off = mask_off + align256(rows);
+    PH_HIP(g_ctx.h_out.reserve(refit_off + (size_t)n_problems * 6 * sizeof(double)));
+    uint8_t *ho = (uint8_t *)g_ctx.h_out.p, *dout = (uint8_t *)g_ctx.h_out.dp;
+    const double *models = (const double *)ho;
+    const int32_t *counts = (const int32_t *)(ho + cnt_off);
+    int32_t *h_beg = (int32_t *)(hi + beg_off), *h_end = (int32_t *)(hi + end_off);
+    int32_t *h_sub = (int32_t *)(hi + sub_off);
+
+    std::vector<int> active;
+    for (;;) {
+        active.clear();
+        int max_left = 0;
+        for (int p = 0; p < n_problems; p++)
+            if (pr[p].live && pr[p].iter < pr[p].niters) {
+                active.push_back(p);
+                max_left = std::max(max_left, pr[p].niters - pr[p].iter);
+            }
+        if (active.empty())
+            break;
+        const int na = (int)active.size();
+        int chunk = std::min(std::max(hyp_target / na, 32), 4096);
+        chunk = std::min(chunk, max_left);
+        // every live problem gets `chunk` slots; slots beyond its budget repeat a valid
+        // sample and are ignored by the replay
+        for (int a = 0; a < na; a++) {
+            Prob &q = pr[active[a]];
+            h_beg[a] = point_offsets[active[a]];
+            h_end[a] = point_offsets[active[a] + 1];
+            const int m = std::min(chunk, q.niters - q.iter);
+            int32_t *sub = h_sub + (size_t)a * chunk * 5;
+            draw_subsets(q.rng, q.n, m, sub);
+            for (int j = m; j < chunk; j++)
+                for (int e = 0; e < 5; e++)
+                    sub[(size_t)j * 5 + e] = e;
+        }
+        PH_HIP(ransac_hypotheses_launch(d_obj, d_img, 0, cam, (const int32_t *)(di + sub_off),
+                                        (const int32_t *)(di + beg_off),
+                                        (const int32_t *)(di + end_off), na, chunk, thr2,
+                                        (double *)dout, (int32_t *)(dout + cnt_off), g_ctx.n_cus,
+                                        st));
+        PH_HIP(hipStreamSynchronize(st));
+        for (int a = 0; a < na; a++) {
+            Prob &q = pr[active[a]];
+            const size_t h0 = (size_t)a * chunk;
+            for (int j = 0; j < chunk && q.iter < q.niters; j++, q.iter++) {
+                const int good = counts[h0 + j];
+                if (good > std::max(q.max_good, model_points - 1)) {
+                    memcpy(q.best, &models[(h0 + j) * 6], sizeof(q.best));
+                    q.max_good = good;
+                    q.niters = update_num_iters(confidence, (double)(q.n - good) / q.n,
+                                                model_points, q.niters);
+                }
+            }
+        }
+    }
+
+    // problems with a model: inlier masks of the best models in one launch
+    std::vector<int> cand;
+    int cand_max_n = 0;
+    double *h_best = (double *)(hi + best_off);
+    for (int p = 0; p < n_problems; p++) {
+        if (iterations_run)
+            iterations_run[p] = pr[p].iter;
+        if (pr[p].live && pr[p].max_good > 0) {
+            const int c = (int)cand.size();
+            h_beg[c] = point_offsets[p];
+            h_end[c] = point_offsets[p + 1];
+            memcpy(h_best + (size_t)c * 6, pr[p].best, sizeof(pr[p].best));
+            cand_max_n = std::max(cand_max_n, pr[p].n);
+            cand.push_back(p);
+        }
+    }
+    if (!cand.empty()) {
+        PH_HIP(inlier_mask_batched_launch(d_obj, d_img, (const int32_t *)(di + beg_off),
+                                          (const int32_t *)(di + end_off), (int)cand.size(),
+                                          cand_max_n, cam, (const double *)(di + best_off), thr2,
+                                          dout + mask_off, st));
+        PH_HIP(hipStreamSynchronize(st));
+    }
+    // refit list: the candidates' inliers, and every row of the five-point problems
+    const uint8_t *mask = ho + mask_off;
+    int32_t *h_rowb = (int32_t *)(hi + rowb_off), *h_ibeg = (int32_t *)(hi + ibeg_off);
+    int32_t *h_icnt = (int32_t *)(hi + icnt_off), *h_idx = (int32_t *)(hi + idx_off);
+    std::vector<int> refit;
+    size_t n_idx = 0;
+    size_t ci = 0;
+    for (int p = 0; p < n_problems; p++) {
+        const bool is_cand = ci < cand.size() && cand[ci] == p;
+        if (is_cand)
+            ci++;
+        if (!is_cand && pr[p].n != model_points)
+            continue;
+        const int r0 = point_offsets[p];
+        const size_t first = n_idx;
+        for (int i = 0; i < pr[p].n; i++)
+            if (!is_cand || mask[(size_t)r0 + i])
+                h_idx[n_idx++] = i;
+        const int k = (int)(n_idx - first);
+        if (k < 4) { // cannot happen with a model of >= 5 inliers
+            n_idx = first;
+            continue;
+        }
+        const int b = (int)refit.size();
+        h_rowb[b] = r0;
+        h_ibeg[b] = (int32_t)first;
+        h_icnt[b] = k;
+        refit.push_back(p);
+    }
+    if (refit.empty())
+        return PH_OK;
+    PH_HIP(g_ctx.pnp_idx.reserve(n_idx * sizeof(int32_t)));
+    PH_HIP(hipMemcpyAsync(g_ctx.pnp_idx.p, h_idx, n_idx * sizeof(int32_t), hipMemcpyHostToDevice,
+                          st));
+    PH_HIP(epnp_solve_batched_launch(d_obj, d_img, (const int32_t *)(di + rowb_off),
+                                     (const int32_t *)g_ctx.pnp_idx.p,
+                                     (const int32_t *)(di + ibeg_off),
+                                     (const int32_t *)(di + icnt_off), (int)refit.size(), cam,
+                                     (double *)(dout + refit_off), st));
+    PH_HIP(hipStreamSynchronize(st));
+    const double *rm = (const double *)(ho + refit_off);
+    for (size_t b = 0; b < refit.size(); b++) {
+        const int p = refit[b];
+        memcpy(rvecs + (size_t)p * 3, rm + b * 6, 3 * sizeof(double));
+        memcpy(tvecs + (size_t)p * 3, rm + b * 6 + 3, 3 * sizeof(double));
+        if (inliers)
+            memcpy(inliers + point_offsets[p], h_idx + h_ibeg[b], (size_t)h_icnt[b] * sizeof(int32_t));
+        if (n_inliers)
+            n_inliers[p] = h_icnt[b];
+        found[p] = 1;
+    }
+    (void)row_lo;
     return PH_OK;
 }
 

@@ -1070,13 +1070,13 @@ __device__ inline Points make_points(const float *obj, const float *img, const i
 // on rows subsets[5h .. 5h+5)) and writes its model (rvec, tvec) to models[6h..].
 // Dynamic LDS: HPW * LDS_DOUBLES doubles.
 // A batch holds n_problems independent problems of hyp_per_problem hypotheses
-// each; problem p owns the correspondence rows [offsets[p], offsets[p+1]) (offsets
-// == nullptr: one problem over all rows) and its subsets index rows of that range.
+// each; problem p owns the correspondence rows [begins[p], ends[p]) (begins ==
+// nullptr: one problem over all rows) and its subsets index rows of that range.
 template <int HPW>
 __global__ __launch_bounds__(64) void ransac_solve_kernel(const float *__restrict__ obj,
                                                           const float *__restrict__ img, CameraK K,
                                                           const int32_t *__restrict__ subsets,
-                                                          const int32_t *__restrict__ offsets,
+                                                          const int32_t *__restrict__ begins,
                                                           int hyp_per_problem, int n_hyp,
                                                           double *__restrict__ models)
 {
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(const float *__restric
     if (lane >= HPW || h >= n_hyp)
         return;
     const EpnpLds<HPW> S(lds + lane);
-    const int64_t row0 = offsets ? offsets[h / hyp_per_problem] : 0;
+    const int64_t row0 = begins ? begins[h / hyp_per_problem] : 0;
     const Points P = make_points(obj + 3 * row0, img + 2 * row0, subsets + (int64_t)h * 5, 5, K);
     double R[3][3], t[3], r[3];
     epnp_pose(P, S, R, t);
@@ -1103,7 +1103,8 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restri
                                                            const float *__restrict__ img, int n,
                                                            CameraK K,
                                                            const double *__restrict__ models,
-                                                           const int32_t *__restrict__ offsets,
+                                                           const int32_t *__restrict__ begins,
+                                                           const int32_t *__restrict__ ends,
                                                            int hyp_per_problem, int n_hyp,
                                                            float thr2, int32_t *__restrict__ counts)
 {
@@ -1111,10 +1112,10 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restri
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= n_hyp)
         return;
-    if (offsets) {
+    if (begins) {
         const int p = h / hyp_per_problem;
-        const int64_t row0 = offsets[p];
-        n = offsets[p + 1] - offsets[p];
+        const int64_t row0 = begins[p];
+        n = ends[p] - begins[p];
         obj += 3 * row0;
         img += 2 * row0;
     }
@@ -1176,9 +1177,59 @@ __global__ __launch_bounds__(64) void epnp_solve_kernel(const float *__restrict_
     }
 }
 
+// Inlier masks of a batch: problem p = blockIdx.y owns rows [begins[p], ends[p]) and
+// the model models[6p..6p+6); mask is indexed by row like obj / img.
+__global__ __launch_bounds__(256) void inlier_mask_batched_kernel(
+    const float *__restrict__ obj, const float *__restrict__ img,
+    const int32_t *__restrict__ begins, const int32_t *__restrict__ ends, CameraK K,
+    const double *__restrict__ models, float thr2, uint8_t *__restrict__ mask)
+{
+    const int p = blockIdx.y;
+    const int64_t row0 = begins[p];
+    const int n = ends[p] - begins[p];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const double *model = models + (int64_t)p * 6;
+    double r[3] = {model[0], model[1], model[2]}, t[3] = {model[3], model[4], model[5]}, R[9];
+    rodrigues_vec_to_mat(r, R);
+    mask[row0 + i] = is_inlier(obj + 3 * row0, img + 2 * row0, i, R, t, K.fx, K.fy, K.cx, K.cy, thr2)
+                         ? 1 : 0;
+}
+
+// epnp_solve_kernel for a batch: workgroup (one wave) b refits problem b on the rows
+// idx[idx_begins[b] .. idx_begins[b] + idx_counts[b]), which are relative to the
+// problem's first row row_begins[b]; models[6b..] = rvec|tvec.
+__global__ __launch_bounds__(64) void epnp_solve_batched_kernel(
+    const float *__restrict__ obj, const float *__restrict__ img,
+    const int32_t *__restrict__ row_begins, const int32_t *__restrict__ idx,
+    const int32_t *__restrict__ idx_begins, const int32_t *__restrict__ idx_counts, CameraK K,
+    double *__restrict__ models)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const EpnpLds<64> S(lds + lane);
+    const int64_t row0 = row_begins[b];
+    const int n = idx_counts[b];
+    Points P = make_points(obj + 3 * row0, img + 2 * row0, idx + idx_begins[b], n, K);
+    if (n >= 64) {
+        P.first = lane;
+        P.step = 64;
+    }
+    double R[3][3], t[3], r[3];
+    epnp_pose(P, S, R, t);
+    rodrigues_mat_to_vec(S, R, r);
+    if (lane == 0) {
+        double *model = models + (int64_t)b * 6;
+        model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
+        model[3] = t[0]; model[4] = t[1]; model[5] = t[2];
+    }
+}
+
 template <int HPW>
 static hipError_t launch_solve(const float *d_obj, const float *d_img, CameraK K,
-                               const int32_t *d_subsets, const int32_t *d_offsets,
+                               const int32_t *d_subsets, const int32_t *d_begins,
                                int hyp_per_problem, int n_hyp, double *d_models,
                                hipStream_t stream)
 {
@@ -1189,14 +1240,14 @@ static hipError_t launch_solve(const float *d_obj, const float *d_img, CameraK K
     if (e != hipSuccess)
         return e;
     ransac_solve_kernel<HPW><<<(n_hyp + HPW - 1) / HPW, 64, lds_bytes, stream>>>(
-        d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp, d_models);
+        d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, n_hyp, d_models);
     return hipGetLastError();
 }
 
 hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int n, CameraK K,
-                                    const int32_t *d_subsets, const int32_t *d_offsets,
-                                    int n_problems, int hyp_per_problem, float thr2,
-                                    double *d_models, int32_t *d_counts, int n_cus,
+                                    const int32_t *d_subsets, const int32_t *d_begins,
+                                    const int32_t *d_ends, int n_problems, int hyp_per_problem,
+                                    float thr2, double *d_models, int32_t *d_counts, int n_cus,
                                     hipStream_t stream)
 {
     const int64_t total = (int64_t)n_problems * hyp_per_problem;
@@ -1211,16 +1262,16 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     // (3 workgroups per CU).
     hipError_t e;
     if (n_hyp <= n_cus * 4 * 16)
-        e = launch_solve<16>(d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp,
+        e = launch_solve<16>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, n_hyp,
                              d_models, stream);
     else
-        e = launch_solve<32>(d_obj, d_img, K, d_subsets, d_offsets, hyp_per_problem, n_hyp,
+        e = launch_solve<32>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, n_hyp,
                              d_models, stream);
     if (e != hipSuccess)
         return e;
     ransac_score_kernel<<<(n_hyp + 3) / 4, 256, 0, stream>>>(d_obj, d_img, n, K, d_models,
-                                                             d_offsets, hyp_per_problem, n_hyp,
-                                                             thr2, d_counts);
+                                                             d_begins, d_ends, hyp_per_problem,
+                                                             n_hyp, thr2, d_counts);
     return hipGetLastError();
 }
 
@@ -1244,6 +1295,39 @@ hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32
     if (e != hipSuccess)
         return e;
     epnp_solve_kernel<<<1, 64, lds_bytes, stream>>>(d_obj, d_img, d_idx, n, K, d_model);
+    return hipGetLastError();
+}
+
+hipError_t inlier_mask_batched_launch(const float *d_obj, const float *d_img,
+                                      const int32_t *d_begins, const int32_t *d_ends,
+                                      int n_problems, int max_n, CameraK K, const double *d_models,
+                                      float thr2, uint8_t *d_mask, hipStream_t stream)
+{
+    if (n_problems <= 0 || max_n <= 0)
+        return hipSuccess;
+    if (n_problems > 65535)
+        return hipErrorInvalidValue;
+    inlier_mask_batched_kernel<<<dim3((unsigned)((max_n + 255) / 256), (unsigned)n_problems), 256, 0,
+                                 stream>>>(d_obj, d_img, d_begins, d_ends, K, d_models, thr2,
+                                           d_mask);
+    return hipGetLastError();
+}
+
+hipError_t epnp_solve_batched_launch(const float *d_obj, const float *d_img,
+                                     const int32_t *d_row_begins, const int32_t *d_idx,
+                                     const int32_t *d_idx_begins, const int32_t *d_idx_counts,
+                                     int n_problems, CameraK K, double *d_models,
+                                     hipStream_t stream)
+{
+    if (n_problems <= 0)
+        return hipSuccess;
+    const size_t lds_bytes = (size_t)64 * LDS_DOUBLES * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void *)epnp_solve_batched_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess)
+        return e;
+    epnp_solve_batched_kernel<<<n_problems, 64, lds_bytes, stream>>>(
+        d_obj, d_img, d_row_begins, d_idx, d_idx_begins, d_idx_counts, K, d_models);
     return hipGetLastError();
 }
 

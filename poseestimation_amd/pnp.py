@@ -83,3 +83,50 @@ def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None,
     if not found.value:
         return False, rvec.reshape(3, 1), tvec.reshape(3, 1), None
     return True, rvec.reshape(3, 1), tvec.reshape(3, 1), inl[:n_inl.value].reshape(-1, 1).copy()
+
+
+def solvePnPRansacBatch(objectPointsList, imagePointsList, cameraMatrix, distCoeffs=None,
+                        iterationsCount=100, reprojectionError=8.0, confidence=0.99,
+                        flags=SOLVEPNP_EPNP, rngState=CV_RNG_DEFAULT_STATE,
+                        returnIterations=False):
+    """solvePnPRansac for a batch of frames in one call: element p of the returned
+    list is what solvePnPRansac(objectPointsList[p], imagePointsList[p], ...) returns
+    (plus the RANSAC iteration count with returnIterations).  A frame with fewer than
+    5 correspondences yields (False, zeros, zeros, None).
+    """
+    if flags != SOLVEPNP_EPNP:
+        raise ValueError("only SOLVEPNP_EPNP is implemented")
+    if len(objectPointsList) != len(imagePointsList):
+        raise ValueError("objectPointsList and imagePointsList differ in length")
+    K = _camera(cameraMatrix, distCoeffs)
+    P = len(objectPointsList)
+    if P == 0:
+        return []
+    objs = [np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3) for o in objectPointsList]
+    imgs = [np.ascontiguousarray(i, dtype=np.float32).reshape(-1, 2) for i in imagePointsList]
+    for o, i in zip(objs, imgs):
+        if o.shape[0] != i.shape[0]:
+            raise ValueError("objectPoints and imagePoints of a frame differ in length")
+    off = np.zeros(P + 1, np.int32)
+    off[1:] = np.cumsum([o.shape[0] for o in objs])
+    total = int(off[-1])
+    obj = np.concatenate(objs) if total else np.zeros((1, 3), np.float32)
+    img = np.concatenate(imgs) if total else np.zeros((1, 2), np.float32)
+    rvecs, tvecs = np.zeros((P, 3)), np.zeros((P, 3))
+    inl = np.zeros(max(total, 1), np.int32)
+    n_inl, found, iters = (np.zeros(P, np.int32) for _ in range(3))
+    i32 = C.POINTER(C.c_int32)
+    _lib.check(_lib.load().ph_solvepnp_ransac_epnp_batched(
+        _fp(obj), _fp(img), off.ctypes.data_as(i32), P, _dp(K), int(iterationsCount),
+        float(reprojectionError), float(confidence), int(rngState), _dp(rvecs), _dp(tvecs),
+        inl.ctypes.data_as(i32), n_inl.ctypes.data_as(i32), found.ctypes.data_as(i32),
+        iters.ctypes.data_as(i32)))
+    out = []
+    for p in range(P):
+        r, t = rvecs[p].reshape(3, 1).copy(), tvecs[p].reshape(3, 1).copy()
+        if found[p]:
+            res = (True, r, t, inl[off[p]:off[p] + n_inl[p]].reshape(-1, 1).copy())
+        else:
+            res = (False, r, t, None)
+        out.append(res + (int(iters[p]),) if returnIterations else res)
+    return out

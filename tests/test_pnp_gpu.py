@@ -208,3 +208,81 @@ def test_scene_to_wireframe_round_trip(posehip):
     ok0, r0, t0, inl0, _ = orc.solvepnp_ransac(pts3d, img, K, iterations=200)
     assert np.array_equal(inliers.ravel(), inl0)
     assert_same_pose(rvec, tvec, r0, t0)
+
+
+def test_batched_solvepnp_ransac_equals_single_calls_and_oracle(posehip):
+    """A ragged batch of frames in one call: every frame must get what its own
+    solvePnPRansac call gets (bit for bit: same kernels, same order of sums) and what
+    the oracle gets (inliers and iteration counts exactly, pose within 1e-4)."""
+    import poseestimation_amd as pa
+    specs = [(2000, 0.3, 3), (500, 0.5, 8), (64, 0.1, 9), (5, 0.0, 11), (300, 1.0, 12), (3, 0.0, 13),
+             (800, 0.2, 14), (1000, 0.6, 15), (6, 0.0, 16)]
+    scenes = [datagen.pnp_scene(n=n, outlier_frac=o, seed=s, noise_px=0.0 if n <= 6 else 1.0)
+              for n, o, s in specs]
+    objs, imgs = [sc[0] for sc in scenes], [sc[1] for sc in scenes]
+    for iters in (100, 1000):
+        res = pa.solvePnPRansacBatch(objs, imgs, datagen.CAMERA_K, None, iterationsCount=iters,
+                                     returnIterations=True)
+        assert len(res) == len(specs)
+        for (n, o, s), obj, img, (ok, rvec, tvec, inl, it) in zip(specs, objs, imgs, res):
+            if n < 5:
+                assert not ok and inl is None and it == 0
+                continue
+            ok1, r1, t1, inl1 = pa.solvePnPRansac(obj, img, datagen.CAMERA_K, None,
+                                                  iterationsCount=iters)
+            assert ok == ok1
+            if ok:
+                assert np.array_equal(inl, inl1)
+                assert np.array_equal(rvec, r1) and np.array_equal(tvec, t1)
+            if n == 5:
+                assert ok and inl.ravel().tolist() == [0, 1, 2, 3, 4] and it == 0
+                continue
+            ok0, r0, t0, inl0, it0 = orc.solvepnp_ransac(obj, img, datagen.CAMERA_K,
+                                                         iterations=iters)
+            assert ok == ok0 and it == it0
+            if ok:
+                assert np.array_equal(inl.ravel(), inl0)
+                assert_same_pose(rvec, tvec, r0, t0)
+
+
+def test_batched_solvepnp_ransac_many_small_frames(posehip):
+    """64 frames of the reference's size (500 correspondences, 100 iterations): more
+    live problems than one round's hypothesis budget per problem, several rounds."""
+    import poseestimation_amd as pa
+    scenes = [datagen.pnp_scene(n=500, outlier_frac=0.25 + 0.005 * f, seed=100 + f)
+              for f in range(64)]
+    res = pa.solvePnPRansacBatch([s[0] for s in scenes], [s[1] for s in scenes], datagen.CAMERA_K,
+                                 None, iterationsCount=1000, returnIterations=True)
+    for f in (0, 17, 63):
+        obj, img = scenes[f][0], scenes[f][1]
+        ok0, r0, t0, inl0, it0 = orc.solvepnp_ransac(obj, img, datagen.CAMERA_K, iterations=1000)
+        ok, rvec, tvec, inl, it = res[f]
+        assert ok == ok0 and it == it0 and np.array_equal(inl.ravel(), inl0)
+        assert_same_pose(rvec, tvec, r0, t0)
+    for (ok, rvec, tvec, inl, it), sc in zip(res, scenes):
+        assert ok
+        assert rel_rotation_error(orc.rodrigues(rvec.ravel()), sc[2]) < 2e-2
+        assert rel_translation_error(tvec.ravel(), sc[3]) < 2e-2
+
+
+def test_batched_solvepnp_ransac_invalid_arguments(posehip):
+    lib = posehip.load()
+    fp, dp, ip = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    obj, img = np.zeros((10, 3), np.float32), np.zeros((10, 2), np.float32)
+    K = np.ascontiguousarray(datagen.CAMERA_K).reshape(9)
+    out = np.zeros(6)
+    i4 = np.zeros(10, np.int32)
+    bad = np.array([0, 10, 5], np.int32)
+    st = lib.ph_solvepnp_ransac_epnp_batched(obj.ctypes.data_as(fp), img.ctypes.data_as(fp),
+                                             bad.ctypes.data_as(ip), 2, K.ctypes.data_as(dp), 100,
+                                             8.0, 0.99, orc.CV_RNG_DEFAULT, out.ctypes.data_as(dp),
+                                             out.ctypes.data_as(dp), i4.ctypes.data_as(ip),
+                                             i4.ctypes.data_as(ip), i4.ctypes.data_as(ip), None)
+    assert st == 1 and b"ascending" in lib.ph_last_error_string()
+    ok = np.array([0, 10], np.int32)
+    st = lib.ph_solvepnp_ransac_epnp_batched(obj.ctypes.data_as(fp), img.ctypes.data_as(fp),
+                                             ok.ctypes.data_as(ip), 1, K.ctypes.data_as(dp), 100,
+                                             8.0, 1.5, orc.CV_RNG_DEFAULT, out.ctypes.data_as(dp),
+                                             out.ctypes.data_as(dp), i4.ctypes.data_as(ip),
+                                             i4.ctypes.data_as(ip), i4.ctypes.data_as(ip), None)
+    assert st == 1   # confidence outside (0, 1)

@@ -49,7 +49,7 @@ int main(int argc, char **argv)
     }
     for (int r = 0; r < 3; r++) {
         CK(hipEventRecord(e0));
-        CK(ransac_hypotheses_launch(d_obj, d_img, n, K, d_sub, nullptr, 1, H, 64.f, d_models, d_counts, 256, 0));
+        CK(ransac_hypotheses_launch(d_obj, d_img, n, K, d_sub, nullptr, nullptr, 1, H, 64.f, d_models, d_counts, 256, 0));
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("H=%d: %.3f ms -> %.3g hyps/s\n", H, ms, H / (ms * 1e-3));
