@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "knn_hamming.h"
@@ -381,6 +382,43 @@ void draw_subsets(uint64_t rng_state, int count, int n_subsets, int32_t *out)
     CvRng rng(rng_state);
     draw_subsets(rng, count, n_subsets, out);
 }
+
+// The sample sequence depends only on (RNG seed, number of correspondences), so it
+// is kept across calls: a video's frames mostly repeat a few hundred distinct
+// correspondence counts, and a repeated count costs no RNG work at all.
+struct SubsetCache {
+    struct Entry {
+        CvRng rng;
+        std::vector<int32_t> subs; // 5 row indices per sample, in drawing order
+    };
+    uint64_t seed = 0;
+    size_t bytes = 0;
+    std::unordered_map<int, Entry> by_count;
+
+    // The first n_subsets samples for `count` correspondences (valid until the next call).
+    const int32_t *get(uint64_t rng_state, int count, int n_subsets)
+    {
+        if (rng_state != seed || bytes > ((size_t)256 << 20)) {
+            by_count.clear();
+            bytes = 0;
+            seed = rng_state;
+        }
+        auto it = by_count.find(count);
+        if (it == by_count.end())
+            it = by_count.emplace(count, Entry{CvRng(rng_state), {}}).first;
+        Entry &e = it->second;
+        const size_t have = e.subs.size() / 5;
+        if (have < (size_t)n_subsets) {
+            // grow geometrically: a budget that shrinks and grows again costs nothing
+            const size_t want = std::max((size_t)n_subsets, have * 2);
+            e.subs.resize(want * 5);
+            draw_subsets(e.rng, count, (int)(want - have), e.subs.data() + have * 5);
+            bytes += (want - have) * 5 * sizeof(int32_t);
+        }
+        return e.subs.data();
+    }
+};
+SubsetCache g_subsets;
 
 // RANSACUpdateNumIters.
 int update_num_iters(double p, double ep, int model_points, int max_iters)
@@ -931,10 +969,9 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
     // over the counts, and chunks beyond the shrunken budget are never launched.
     int niters = std::max(iterations_count, 1);
     const int total = niters;
-    std::vector<int32_t> subsets((size_t)total * 5);
-    draw_subsets(rng_state, n, total, subsets.data());
+    const int32_t *subsets = g_subsets.get(rng_state, n, total);
     PnpDev d;
-    if ((s = upload_pnp(obj, img, n, subsets.data(), (size_t)total, st, d)) != PH_OK)
+    if ((s = upload_pnp(obj, img, n, subsets, (size_t)total, st, d)) != PH_OK)
         return s;
     // pinned results, written by the kernels: models | counts | mask | refit model
     const int chunk = 4096, cmax = std::min(total, chunk);
@@ -1054,7 +1091,6 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
     hipStream_t st = g_ctx.stream;
 
     struct Prob {
-        CvRng rng;
         int n, niters, iter = 0, max_good = 0;
         double best[6] = {0, 0, 0, 0, 0, 0};
         bool live;
@@ -1062,7 +1098,7 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
     std::vector<Prob> pr;
     pr.reserve((size_t)n_problems);
     for (int p = 0; p < n_problems; p++) {
-        Prob q{CvRng(rng_state)};
+        Prob q{};
         q.n = point_offsets[p + 1] - point_offsets[p];
         q.niters = std::max(iterations_count, 1);
         q.live = q.n > model_points; // fewer: no pose; exactly five: one solve, no sampling
@@ -1070,7 +1106,7 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
     }
 
     // Hypotheses per round: enough to fill the GPU, shared by the live problems.
-    const int hyp_target = g_ctx.n_cus * 96;
+    const int hyp_target = g_ctx.n_cus * 128;
     const size_t cap_hyps = (size_t)std::max(hyp_target, n_problems * 32);
     // pinned input area: obj | img staging, then small tables the kernels read in place
     const size_t rows = (size_t)row_hi;
@@ -1123,7 +1159,8 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
             h_end[a] = point_offsets[active[a] + 1];
             const int m = std::min(chunk, q.niters - q.iter);
             int32_t *sub = h_sub + (size_t)a * chunk * 5;
-            draw_subsets(q.rng, q.n, m, sub);
+            memcpy(sub, g_subsets.get(rng_state, q.n, q.iter + m) + (size_t)q.iter * 5,
+                   (size_t)m * 5 * sizeof(int32_t));
             for (int j = m; j < chunk; j++)
                 for (int e = 0; e < 5; e++)
                     sub[(size_t)j * 5 + e] = e;

@@ -14,7 +14,7 @@
 // ONE HYPOTHESIS PER LANE: every instruction of that chain serves up to 64
 // hypotheses.  Each lane keeps its small matrices (12 x 12 null-space problem,
 // 6 x 10 system, ...) in LDS, interleaved over the lanes (element e of lane l at
-// word e*HPW + l, so a wave access is conflict-free), 1632 bytes per hypothesis.
+// word e*HPW + l, so a wave access is conflict-free), 1248 bytes per hypothesis.
 // Every operation is in the order of a plain sequential statement of the
 // algorithm (built with -ffp-contract=off) so that poses agree with a CPU
 // statement to the last bits.  Per-point quantities (barycentric coordinates,
@@ -393,28 +393,30 @@ template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
 }
 
 // A lane's LDS arrays (offsets in doubles; LDS_DOUBLES per hypothesis).  Lifetimes
-// overlap so that the peak is the 12 x 12 matrix plus the small-SVD scratch:
-//   ut  12 x 12: MtM, then its left singular vectors (rows); only rows 8..11
-//       (elements 96..143) are read after the decomposition, so
-//   l   (6 x 10) and ga (6 x 4 Gauss-Newton matrix) live in ut[0..84) from then on;
-//   sa/sv/sw  scratch of the small SVDs (At up to 5 x 6, Vt up to 5 x 5, W);
-//   w   the 12 row norms of the big decomposition, which shares sa (no small SVD
-//       runs meanwhile).
+// overlap so that the peak is the 12 x 12 matrix plus its 12 row norms:
+//   ut  12 x 12: MtM, then its left singular vectors (rows), with w = the row norms.
+//       Only rows 8..11 are read after the decomposition: row 11 moves to registers
+//       and rows 8..10 to v (the last 36 doubles), which frees ut[0..120) for
+//   l   6 x 10, and the scratch of the small SVDs sa / sv / sw (At up to 5 x 6, Vt up
+//       to 5 x 5, W), which also serve the control-point and basis steps that run
+//       before MtM is formed;
+//   ga  the 6 x 4 Gauss-Newton matrix shares sa (no small SVD runs meanwhile).
 constexpr int OFF_UT = 0;
-constexpr int OFF_L = 0;
-constexpr int OFF_GA = 60;
-constexpr int OFF_SA = 144;  // 30
+constexpr int OFF_L = 0;     // 60
+constexpr int OFF_SA = 60;   // 30
+constexpr int OFF_GA = 60;   // 24
+constexpr int OFF_SV = 90;   // 25
+constexpr int OFF_SW = 115;  // 5
+constexpr int OFF_V = 120;   // 36: rows 8, 9, 10 of ut
 constexpr int OFF_W = 144;   // 12
-constexpr int OFF_SV = 174;  // 25
-constexpr int OFF_SW = 199;  // 5
-constexpr int LDS_DOUBLES = 204; // 32 hypotheses = 51 KiB: three workgroups per CU
+constexpr int LDS_DOUBLES = 156; // 32 hypotheses = 39 KiB: four workgroups per CU
 
 template <int ST> struct EpnpLds {
-    LP<ST> ut, w, sa, sv, sw, l, ga;
+    LP<ST> ut, w, sa, sv, sw, l, ga, v;
     __device__ explicit EpnpLds(double *lane_base)
         : ut{lane_base + OFF_UT * ST}, w{lane_base + OFF_W * ST}, sa{lane_base + OFF_SA * ST},
           sv{lane_base + OFF_SV * ST}, sw{lane_base + OFF_SW * ST}, l{lane_base + OFF_L * ST},
-          ga{lane_base + OFF_GA * ST}
+          ga{lane_base + OFF_GA * ST}, v{lane_base + OFF_V * ST}
     {
     }
 };
@@ -639,16 +641,37 @@ __device__ void accumulate_mtm(const Points &P, const EpnpState &e, const EpnpLd
         }
 }
 
-template <int ST> __device__ void compute_L_6x10(LP<ST> ut, LP<ST> l)
+// The null-space rows of ut, detached from it: row 11 in registers, rows 8..10 in
+// S.v.  element(i, k) = ut[(11 - i) * 12 + k], i.e. i counts from the smallest
+// singular value as EPnP does.
+template <int ST> struct NullRows {
+    double v11[12];
+    LP<ST> v;
+    __device__ double at(int i, int k) const { return i == 0 ? v11[k] : v[(3 - i) * 12 + k]; }
+};
+
+template <int ST> __device__ void detach_null_rows(const EpnpLds<ST> &S, NullRows<ST> &N)
 {
-    const LP<ST> v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
+    N.v = S.v;
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+        N.v11[k] = S.ut[11 * 12 + k];
+    // rows 8..10 (ut[96..132)) -> v (ut[120..156)): overlapping, so copy from the top
+    for (int e = 35; e >= 0; e--)
+        S.v[e] = S.ut[96 + e];
+}
+
+template <int ST> __device__ void compute_L_6x10(const NullRows<ST> &N, LP<ST> l)
+{
     double dv[4][6][3];
+#pragma unroll
     for (int i = 0; i < 4; i++) {
         int a = 0, b = 1;
+#pragma unroll
         for (int j = 0; j < 6; j++) {
-            dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
-            dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
-            dv[i][j][2] = v[i][3 * a + 2] - v[i][3 * b + 2];
+            dv[i][j][0] = N.at(i, 3 * a) - N.at(i, 3 * b);
+            dv[i][j][1] = N.at(i, 3 * a + 1) - N.at(i, 3 * b + 1);
+            dv[i][j][2] = N.at(i, 3 * a + 2) - N.at(i, 3 * b + 2);
             b++;
             if (b > 3) {
                 a++;
@@ -819,16 +842,19 @@ __device__ void gauss_newton(const EpnpLds<ST> &S, const double *rho, double *bt
 // compute_ccs, compute_pcs, solve_for_sign, estimate_R_and_t, reprojection_error.
 template <int ST>
 __device__ double compute_R_and_t(const Points &P, EpnpState &e, const EpnpLds<ST> &S,
-                                  const double *betas, double R[3][3], double t[3])
+                                  const NullRows<ST> &N, const double *betas, double R[3][3],
+                                  double t[3])
 {
     const int n = P.n;
     for (int i = 0; i < 4; i++)
         e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0f;
+#pragma unroll
     for (int i = 0; i < 4; i++) {
-        const LP<ST> v = S.ut + 12 * (11 - i);
+#pragma unroll
         for (int j = 0; j < 4; j++)
+#pragma unroll
             for (int k = 0; k < 3; k++)
-                e.ccs[j][k] += betas[i] * v[3 * j + k];
+                e.ccs[j][k] += betas[i] * N.at(i, 3 * j + k);
     }
     // solve_for_sign: the first point's depth decides the sign of everything
     {
@@ -925,7 +951,9 @@ __device__ void epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3],
     // MtM is symmetric, so it is its own transposed copy; EPnP reads only U
     jacobi_svd_12<ST>(S.ut, S.w);
     PNP_STAMP(4);
-    compute_L_6x10(S.ut, S.l);
+    NullRows<ST> N;
+    detach_null_rows(S, N);
+    compute_L_6x10(N, S.l);
     PNP_STAMP(5);
     double rho[6];
     rho[0] = dist2(e.cws[0], e.cws[1]);
@@ -941,7 +969,7 @@ __device__ void epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3],
         PNP_STAMP(6 + 3 * (c - 1));
         gauss_newton(S, rho, betas);
         PNP_STAMP(7 + 3 * (c - 1));
-        const double err = compute_R_and_t(P, e, S, betas, Rc, tc);
+        const double err = compute_R_and_t(P, e, S, N, betas, Rc, tc);
         PNP_STAMP(8 + 3 * (c - 1));
         // N = 1; if (err2 < err1) N = 2; if (err3 < err[N]) N = 3
         if (c == 1 || err < best_err) {
@@ -1256,10 +1284,10 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     if (total > 0x7FFFFFFF)
         return hipErrorInvalidValue;
     const int n_hyp = (int)total;
-    // Hypotheses per wave: the solve is latency-bound and LDS capacity (1632 B per
-    // hypothesis -> 96 per CU) sets how many are in flight, so few hypotheses go
-    // 16 to a wave (as many CUs and SIMDs as possible) and many go 32 to a wave
-    // (3 workgroups per CU).
+    // Hypotheses per wave: one wave's fp64 instruction stream keeps its SIMD busy, and
+    // LDS capacity (1248 B per hypothesis -> 128 per CU) sets how many hypotheses are
+    // in flight, so few hypotheses go 16 to a wave (as many CUs and SIMDs as
+    // possible) and many go 32 to a wave (4 workgroups per CU, one per SIMD).
     hipError_t e;
     if (n_hyp <= n_cus * 4 * 16)
         e = launch_solve<16>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, n_hyp,
