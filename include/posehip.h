@@ -135,6 +135,16 @@ ph_status ph_knn_hamming256_frames_dev(const void *d_query, const int32_t *q_off
                                        int32_t *d_out_dist, uint8_t *d_keep, float ratio,
                                        void *stream);
 
+/* Cross-check match for a batch of frames in one launch: per frame the result of
+ * ph_match_crosscheck_hamming256_dev (BFMatcher(NORM_HAMMING, crossCheck=true)
+ * .match of src/orb_feature_matching/matcher.py:18,21), frames laid out as for
+ * ph_knn_hamming256_frames_dev.  d_out_idx / d_out_dist are indexed by query row of
+ * d_query (not compacted); train indices are relative to the frame. */
+ph_status ph_match_crosscheck_hamming256_frames_dev(const void *d_query, const int32_t *q_offsets,
+                                                    const void *d_train, const int32_t *t_offsets,
+                                                    int n_frames, int32_t *d_out_idx,
+                                                    int32_t *d_out_dist, void *stream);
+
 /* Merge per-shard k-NN candidate lists (the step after the all-gather of a
  * train-sharded search).  d_cand_idx / d_cand_dist: [n_shards][nq][k], shards
  * ordered by ascending train index range, indices global.  Output as

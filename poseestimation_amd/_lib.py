@@ -53,6 +53,9 @@ SIGNATURES = {
     "ph_knn_hamming256_frames_dev": (C.c_int, [C.c_void_p, _i32p, C.c_void_p, _i32p, C.c_int,
                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_float, C.c_void_p]),
+    "ph_match_crosscheck_hamming256_frames_dev": (C.c_int, [C.c_void_p, _i32p, C.c_void_p, _i32p,
+                                                            C.c_int, C.c_void_p, C.c_void_p,
+                                                            C.c_void_p]),
     "ph_knn_merge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "ph_match_crosscheck_hamming256_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,

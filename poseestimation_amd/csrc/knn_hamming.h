@@ -62,4 +62,14 @@ hipError_t crosscheck_resolve_launch(const int32_t *d_tidx, const int32_t *d_tdi
                                      int64_t nq, unsigned long long *d_best, int32_t *d_out_idx,
                                      int32_t *d_out_dist, hipStream_t stream);
 
+// The same for a batch of frames: d_tidx / d_tdist indexed by train row of the whole
+// buffer (frame-local query indices), outputs by query row (frame-local train indices);
+// query rows [row_begin, row_end) are written.
+hipError_t crosscheck_resolve_frames_launch(const int32_t *d_tidx, const int32_t *d_tdist,
+                                            const int32_t *d_q_off, const int32_t *d_t_off,
+                                            int n_frames, int64_t max_nt, int64_t row_begin,
+                                            int64_t row_end, unsigned long long *d_best,
+                                            int32_t *d_out_idx, int32_t *d_out_dist,
+                                            hipStream_t stream);
+
 } // namespace posehip

@@ -456,6 +456,27 @@ __global__ __launch_bounds__(256) void cc_finalize_kernel(
     out_dist[i] = b == ~0ull ? 0x7FFFFFFF : (int32_t)(b >> 32);
 }
 
+// The scatter step for a batch of frames (grid.y = frame): tidx / tdist are indexed by
+// train row of the whole buffer and hold query indices local to the frame; best is
+// indexed by query row of the whole buffer and receives frame-local train indices.
+__global__ __launch_bounds__(256) void cc_scatter_frames_kernel(
+    const int32_t *__restrict__ tidx, const int32_t *__restrict__ tdist,
+    const int32_t *__restrict__ q_off, const int32_t *__restrict__ t_off,
+    unsigned long long *__restrict__ best)
+{
+    const int f = blockIdx.y;
+    const int64_t t0 = t_off[f], nt = t_off[f + 1] - t0;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nt)
+        return;
+    const int32_t q = tidx[t0 + i];
+    if (q < 0)
+        return;
+    const unsigned long long key =
+        ((unsigned long long)(uint32_t)tdist[t0 + i] << 32) | (uint32_t)i;
+    atomicMin(&best[(int64_t)q_off[f] + q], key);
+}
+
 // ---- launchers ---------------------------------------------------------------
 
 KnnPlan knn_plan_splits(int64_t nq, int64_t nt, int waves, bool lazy, int64_t splits)
@@ -698,6 +719,25 @@ hipError_t crosscheck_resolve_launch(const int32_t *d_tidx, const int32_t *d_tdi
                                                                          d_best);
     cc_finalize_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, stream>>>(d_best, nq, d_out_idx,
                                                                           d_out_dist);
+    return hipGetLastError();
+}
+
+hipError_t crosscheck_resolve_frames_launch(const int32_t *d_tidx, const int32_t *d_tdist,
+                                            const int32_t *d_q_off, const int32_t *d_t_off,
+                                            int n_frames, int64_t max_nt, int64_t row_begin,
+                                            int64_t row_end, unsigned long long *d_best,
+                                            int32_t *d_out_idx, int32_t *d_out_dist,
+                                            hipStream_t stream)
+{
+    const int64_t rows = row_end - row_begin;
+    if (rows <= 0)
+        return hipSuccess;
+    cc_init_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, stream>>>(d_best + row_begin, rows);
+    if (max_nt > 0)
+        cc_scatter_frames_kernel<<<dim3((unsigned)((max_nt + 255) / 256), (unsigned)n_frames), 256,
+                                   0, stream>>>(d_tidx, d_tdist, d_q_off, d_t_off, d_best);
+    cc_finalize_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, stream>>>(
+        d_best + row_begin, rows, d_out_idx + row_begin, d_out_dist + row_begin);
     return hipGetLastError();
 }
 

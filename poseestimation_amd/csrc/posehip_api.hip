@@ -342,6 +342,60 @@ ph_status check_host_args(const uint8_t *q, int nq, size_t q_step, const uint8_t
     return PH_OK;
 }
 
+// ---- batches of frames -----------------------------------------------------------
+struct FrameBatch {
+    int64_t max_nq = 0, max_nt = 0;
+    int64_t q_begin = 0, q_end = 0, t_end = 0;
+    const int32_t *d_q_off = nullptr, *d_t_off = nullptr; // device copies of the tables
+};
+
+ph_status check_frames(const int32_t *q_offsets, const int32_t *t_offsets, int n_frames,
+                       FrameBatch &fb)
+{
+    if (n_frames < 0 || n_frames > 65535)
+        return fail(PH_ERR_INVALID_ARG, "n_frames must be in 0..65535 (got %d)", n_frames);
+    if (n_frames == 0)
+        return PH_OK;
+    if (!q_offsets || !t_offsets)
+        return fail(PH_ERR_INVALID_ARG, "null offset table");
+    if (q_offsets[0] < 0 || t_offsets[0] < 0)
+        return fail(PH_ERR_INVALID_ARG, "negative offset");
+    for (int f = 0; f < n_frames; f++) {
+        const int64_t a = (int64_t)q_offsets[f + 1] - q_offsets[f];
+        const int64_t b = (int64_t)t_offsets[f + 1] - t_offsets[f];
+        if (a < 0 || b < 0)
+            return fail(PH_ERR_INVALID_ARG, "offsets of frame %d are not ascending", f);
+        fb.max_nq = std::max(fb.max_nq, a);
+        fb.max_nt = std::max(fb.max_nt, b);
+    }
+    fb.q_begin = q_offsets[0];
+    fb.q_end = q_offsets[n_frames];
+    fb.t_end = t_offsets[n_frames];
+    return PH_OK;
+}
+
+// Offset tables: host -> a pinned ring slot -> device, in stream order.  The caller
+// records slot->done on the stream behind the last kernel that reads the tables.
+ph_status upload_frame_tables(const int32_t *q_offsets, const int32_t *t_offsets, int n_frames,
+                              hipStream_t st, FrameBatch &fb, Context::OffsetSlot *&slot)
+{
+    slot = &g_ctx.off_ring[g_ctx.off_next];
+    g_ctx.off_next = (g_ctx.off_next + 1) % 4;
+    if (!slot->done)
+        PH_HIP(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+    else
+        PH_HIP(hipEventSynchronize(slot->done));
+    const size_t tab = (size_t)(n_frames + 1) * sizeof(int32_t);
+    PH_HIP(slot->h.reserve(2 * tab));
+    PH_HIP(slot->d.reserve(2 * tab));
+    memcpy(slot->h.p, q_offsets, tab);
+    memcpy((uint8_t *)slot->h.p + tab, t_offsets, tab);
+    PH_HIP(hipMemcpyAsync(slot->d.p, slot->h.p, 2 * tab, hipMemcpyHostToDevice, st));
+    fb.d_q_off = (const int32_t *)slot->d.p;
+    fb.d_t_off = fb.d_q_off + (n_frames + 1);
+    return PH_OK;
+}
+
 // ---- RANSAC host logic ------------------------------------------------------------
 // cv::RNG: multiply-with-carry, state = lo32 * 4164903690 + hi32.
 struct CvRng {
@@ -616,66 +670,93 @@ ph_status ph_knn_hamming256_frames_dev(const void *d_query, const int32_t *q_off
         return fail(PH_ERR_INVALID_ARG, "k must be 1 or 2 (got %d)", k);
     if (d_keep && k != 2)
         return fail(PH_ERR_INVALID_ARG, "the ratio test needs k == 2");
-    if (n_frames < 0 || n_frames > 65535)
-        return fail(PH_ERR_INVALID_ARG, "n_frames must be in 0..65535 (got %d)", n_frames);
-    if (n_frames == 0)
+    FrameBatch fb;
+    if ((s = check_frames(q_offsets, t_offsets, n_frames, fb)) != PH_OK)
+        return s;
+    if (fb.q_end == fb.q_begin)
         return PH_OK;
-    if (!q_offsets || !t_offsets)
-        return fail(PH_ERR_INVALID_ARG, "null offset table");
-    if (q_offsets[0] < 0 || t_offsets[0] < 0)
-        return fail(PH_ERR_INVALID_ARG, "negative offset");
-    int64_t max_nq = 0, max_nt = 0;
-    for (int f = 0; f < n_frames; f++) {
-        const int64_t a = (int64_t)q_offsets[f + 1] - q_offsets[f];
-        const int64_t b = (int64_t)t_offsets[f + 1] - t_offsets[f];
-        if (a < 0 || b < 0)
-            return fail(PH_ERR_INVALID_ARG, "offsets of frame %d are not ascending", f);
-        max_nq = std::max(max_nq, a);
-        max_nt = std::max(max_nt, b);
-    }
-    const int64_t row_begin = q_offsets[0], row_end = q_offsets[n_frames];
-    if (row_end == row_begin)
-        return PH_OK;
-    if (!d_query || !d_out_idx || !d_out_dist || (max_nt > 0 && !d_train))
+    if (!d_query || !d_out_idx || !d_out_dist || (fb.max_nt > 0 && !d_train))
         return fail(PH_ERR_INVALID_ARG, "null pointer");
     hipStream_t st = pick_stream(stream);
-    if (max_nt == 0) {
-        const int64_t rows = row_end - row_begin;
+    if (fb.max_nt == 0) {
+        const int64_t rows = fb.q_end - fb.q_begin;
         fill_empty_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, st>>>(
-            d_out_idx + row_begin * k, d_out_dist + row_begin * k,
-            d_keep ? d_keep + row_begin : nullptr, rows, k);
+            d_out_idx + fb.q_begin * k, d_out_dist + fb.q_begin * k,
+            d_keep ? d_keep + fb.q_begin : nullptr, rows, k);
         PH_HIP(hipGetLastError());
         return PH_OK;
     }
     if (((uintptr_t)d_query & 15) || ((uintptr_t)d_train & 15))
         return fail(PH_ERR_INVALID_ARG, "descriptor buffers must be 16-byte aligned");
-    const KnnPlan plan = knn_plan_frames(n_frames, max_nq, max_nt, row_end, g_ctx.n_cus);
-    if (frame_rows_per_split(max_nt, plan) * (int64_t)plan.n_splits < max_nt)
+    const KnnPlan plan = knn_plan_frames(n_frames, fb.max_nq, fb.max_nt, fb.q_end, g_ctx.n_cus);
+    if (frame_rows_per_split(fb.max_nt, plan) * (int64_t)plan.n_splits < fb.max_nt)
         return fail(PH_ERR_TOO_LARGE, "train set of %lld rows is too large for one call",
-                    (long long)max_nt);
+                    (long long)fb.max_nt);
     if ((s = scratch_guard(st)) != PH_OK)
         return s;
     PH_HIP(g_ctx.part.reserve(plan.part_bytes));
-    // offsets: host -> pinned slot -> device, in stream order
-    Context::OffsetSlot &slot = g_ctx.off_ring[g_ctx.off_next];
-    g_ctx.off_next = (g_ctx.off_next + 1) % 4;
-    if (!slot.done)
-        PH_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
-    else
-        PH_HIP(hipEventSynchronize(slot.done));
-    const size_t tab = (size_t)(n_frames + 1) * sizeof(int32_t);
-    PH_HIP(slot.h.reserve(2 * tab));
-    PH_HIP(slot.d.reserve(2 * tab));
-    memcpy(slot.h.p, q_offsets, tab);
-    memcpy((uint8_t *)slot.h.p + tab, t_offsets, tab);
-    PH_HIP(hipMemcpyAsync(slot.d.p, slot.h.p, 2 * tab, hipMemcpyHostToDevice, st));
-    const int32_t *d_q_off = (const int32_t *)slot.d.p, *d_t_off = d_q_off + (n_frames + 1);
+    Context::OffsetSlot *slot = nullptr;
+    if ((s = upload_frame_tables(q_offsets, t_offsets, n_frames, st, fb, slot)) != PH_OK)
+        return s;
     hipEvent_t *ev = g_ctx.profiling ? g_ctx.ev : nullptr;
-    PH_HIP(knn_frames_launch(plan, d_query, d_q_off, d_train, d_t_off, n_frames, row_end, k,
+    PH_HIP(knn_frames_launch(plan, d_query, fb.d_q_off, d_train, fb.d_t_off, n_frames, fb.q_end, k,
                              (uint32_t *)g_ctx.part.p, d_out_idx, d_out_dist, d_keep, ratio, st,
                              ev));
-    PH_HIP(hipEventRecord(slot.done, st));
+    PH_HIP(hipEventRecord(slot->done, st));
     g_ctx.ev_valid = ev != nullptr;
+    return PH_OK;
+}
+
+ph_status ph_match_crosscheck_hamming256_frames_dev(const void *d_query, const int32_t *q_offsets,
+                                                    const void *d_train, const int32_t *t_offsets,
+                                                    int n_frames, int32_t *d_out_idx,
+                                                    int32_t *d_out_dist, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    FrameBatch fb;
+    if ((s = check_frames(q_offsets, t_offsets, n_frames, fb)) != PH_OK)
+        return s;
+    if (fb.q_end == fb.q_begin)
+        return PH_OK;
+    if (!d_query || !d_out_idx || !d_out_dist || (fb.max_nt > 0 && !d_train))
+        return fail(PH_ERR_INVALID_ARG, "null pointer");
+    hipStream_t st = pick_stream(stream);
+    if (fb.max_nt == 0) {
+        const int64_t rows = fb.q_end - fb.q_begin;
+        fill_empty_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, st>>>(
+            d_out_idx + fb.q_begin, d_out_dist + fb.q_begin, nullptr, rows, 1);
+        PH_HIP(hipGetLastError());
+        return PH_OK;
+    }
+    if (((uintptr_t)d_query & 15) || ((uintptr_t)d_train & 15))
+        return fail(PH_ERR_INVALID_ARG, "descriptor buffers must be 16-byte aligned");
+    // Roles swapped: every train row finds its nearest query row of its own frame.
+    const KnnPlan plan = knn_plan_frames(n_frames, fb.max_nt, fb.max_nq, fb.t_end, g_ctx.n_cus);
+    if (fb.max_nq > 0 &&
+        frame_rows_per_split(fb.max_nq, plan) * (int64_t)plan.n_splits < fb.max_nq)
+        return fail(PH_ERR_TOO_LARGE, "query set of %lld rows is too large for one call",
+                    (long long)fb.max_nq);
+    if ((s = scratch_guard(st)) != PH_OK)
+        return s;
+    PH_HIP(g_ctx.part2.reserve(plan.part_bytes));
+    PH_HIP(g_ctx.tmp_i.reserve((size_t)fb.t_end * sizeof(int32_t)));
+    PH_HIP(g_ctx.tmp_d.reserve((size_t)fb.t_end * sizeof(int32_t)));
+    PH_HIP(g_ctx.best.reserve((size_t)fb.q_end * sizeof(unsigned long long)));
+    Context::OffsetSlot *slot = nullptr;
+    if ((s = upload_frame_tables(q_offsets, t_offsets, n_frames, st, fb, slot)) != PH_OK)
+        return s;
+    PH_HIP(knn_frames_launch(plan, d_train, fb.d_t_off, d_query, fb.d_q_off, n_frames, fb.t_end, 1,
+                             (uint32_t *)g_ctx.part2.p, (int32_t *)g_ctx.tmp_i.p,
+                             (int32_t *)g_ctx.tmp_d.p, nullptr, 0.f, st, nullptr));
+    PH_HIP(crosscheck_resolve_frames_launch((const int32_t *)g_ctx.tmp_i.p,
+                                            (const int32_t *)g_ctx.tmp_d.p, fb.d_q_off, fb.d_t_off,
+                                            n_frames, fb.max_nt, fb.q_begin, fb.q_end,
+                                            (unsigned long long *)g_ctx.best.p, d_out_idx,
+                                            d_out_dist, st));
+    PH_HIP(hipEventRecord(slot->done, st));
     return PH_OK;
 }
 

@@ -130,3 +130,29 @@ def knn_frames(d_query, q_offsets, d_train, t_offsets, k, ratio=None):
         keep.data_ptr() if keep is not None else None,
         float(ratio) if ratio is not None else 0.0, sp))
     return idx, dst, keep
+
+
+def match_crosscheck_frames(d_query, q_offsets, d_train, t_offsets):
+    """Cross-check match (BFMatcher(NORM_HAMMING, crossCheck=True).match) of a batch of
+    frames in one launch; frames are laid out as for knn_frames.  Returns (idx [rows],
+    dist [rows]) indexed by query row: the matched frame-local train row or -1."""
+    import numpy as np
+    lib = _lib.load()
+    qo = np.ascontiguousarray(q_offsets, dtype=np.int32)
+    to = np.ascontiguousarray(t_offsets, dtype=np.int32)
+    if qo.ndim != 1 or qo.shape != to.shape or qo.size < 1:
+        raise ValueError("q_offsets and t_offsets must be 1-D and of equal length >= 1")
+    if qo.size > 1 and (int(qo[-1]) > d_query.shape[0] or int(to[-1]) > d_train.shape[0]):
+        raise ValueError("offsets exceed the descriptor buffers")
+    sp = _stream_ptr()
+    if sp is None:
+        raise RuntimeError("run under `with torch.cuda.stream(torch.cuda.Stream())`: torch's "
+                           "default stream has no handle to pass through the C ABI")
+    rows, dev = d_query.shape[0], d_query.device
+    idx = torch.full((rows,), -1, dtype=torch.int32, device=dev)
+    dst = torch.full((rows,), 2147483647, dtype=torch.int32, device=dev)
+    i32p = C.POINTER(C.c_int32)
+    _lib.check(lib.ph_match_crosscheck_hamming256_frames_dev(
+        d_query.data_ptr(), qo.ctypes.data_as(i32p), d_train.data_ptr(), to.ctypes.data_as(i32p),
+        qo.size - 1, idx.data_ptr(), dst.data_ptr(), sp))
+    return idx, dst

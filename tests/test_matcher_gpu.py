@@ -519,3 +519,32 @@ def test_calls_on_two_streams_are_ordered(posehip):
         ri, rd = orc.knn(x, t, 2, threads=8)
         assert np.array_equal(outs[i][0].cpu().numpy(), ri)
         assert np.array_equal(outs[i][1].cpu().numpy(), rd)
+
+
+@pytest.mark.parametrize("tie_stress", [False, True])
+def test_crosscheck_frames(posehip, tie_stress):
+    """Cross-check match of ragged frames in one launch against the oracle per frame."""
+    import torch
+    from poseestimation_amd import distributed as D
+    nqs = [500, 0, 64, 65, 1, 300, 777, 129]
+    nts = [431, 50, 1, 3, 1000, 0, 2051, 64]
+    qo, to = np.concatenate([[0], np.cumsum(nqs)]), np.concatenate([[0], np.cumsum(nts)])
+    if tie_stress:
+        q = datagen.codebook_descriptors(int(qo[-1]), 81, words=64)
+        t = datagen.codebook_descriptors(int(to[-1]), 82, words=64)
+    else:
+        t = datagen.random_descriptors(int(to[-1]), 83)
+        q = datagen.random_descriptors(int(qo[-1]), 84)
+        q[:431] = datagen.perturbed_copy(t[:431], 85, max_flips=30)   # frame 0 has true matches
+    with torch.cuda.stream(torch.cuda.Stream()):
+        idx, dist = D.match_crosscheck_frames(_dev(q), qo, _dev(t), to)
+        torch.cuda.current_stream().synchronize()
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    for f in range(len(nqs)):
+        want_i = np.full(nqs[f], -1, np.int32)
+        want_d = np.full(nqs[f], INT_MAX, np.int32)
+        if nqs[f] and nts[f]:
+            for qi, ti, _, d in orc.match(q[qo[f]:qo[f + 1]], t[to[f]:to[f + 1]], cross_check=True):
+                want_i[qi], want_d[qi] = ti, int(d)
+        assert np.array_equal(idx[qo[f]:qo[f + 1]], want_i), f
+        assert np.array_equal(dist[qo[f]:qo[f + 1]], want_d), f
