@@ -76,18 +76,34 @@ if "C1" not in args.skip:
     p_s = timed(lambda: pa.solvePnPRansac(obj, img, datagen.CAMERA_K, None, iterationsCount=100), 10)
     c0 = time.perf_counter(); [orc.match(q, t, cross_check=True) for _ in range(20)]; cm = (time.perf_counter() - c0) / 20
     c0 = time.perf_counter(); [orc.solvepnp_ransac(obj, img, datagen.CAMERA_K, iterations=100) for _ in range(20)]; cp = (time.perf_counter() - c0) / 20
+    # the same work for 256 frames at once: one batched cross-check launch (device buffers)
+    # and one batched solvePnPRansac call (host buffers)
+    from poseestimation_amd import distributed as D
+    FB = 256
+    d_qb, d_tb = gpu_rand_descriptors(FB * 500, 11), gpu_rand_descriptors(FB * 500, 12)
+    offs = np.arange(FB + 1) * 500
+    mb_s = timed(lambda: D.match_crosscheck_frames(d_qb, offs, d_tb, offs), 10)
+    scenes = [datagen.pnp_scene(n=500, outlier_frac=0.3, seed=300 + f) for f in range(FB)]
+    fo, fi = [x[0] for x in scenes], [x[1] for x in scenes]
+    pb_s = timed(lambda: pa.solvePnPRansacBatch(fo, fi, datagen.CAMERA_K, None, iterationsCount=100), 5)
     out.append({"config": "C1 500x500 crossCheck match + solvePnPRansac(100 iters, 500 pairs), host buffers, latency",
                 "gpu_match_us": m_s * 1e6, "gpu_pnp_us": p_s * 1e6, "cpu_match_us": cm * 1e6, "cpu_pnp_us": cp * 1e6,
+                "gpu_256_frames_batched": {"match_us_per_frame": mb_s / FB * 1e6, "pnp_us_per_frame": pb_s / FB * 1e6},
                 "cpu": "oracle, 1 thread", "note": "launch/copy-latency bound on the GPU; the CPU's sequential RANSAC stops after ~25 iterations"})
 
 if "C2" not in args.skip:
+    from poseestimation_amd import distributed as D2
     d_q, d_t = gpu_rand_descriptors(10000, 2), gpu_rand_descriptors(10000, 102)
     d_i = torch.empty((10000, 2), dtype=torch.int32, device=dev); d_d = torch.empty_like(d_i)
     d_k = torch.empty(10000, dtype=torch.uint8, device=dev)
     s = timed(lambda: [knn_dev(d_q, d_t, 2, d_i, d_d, d_k, 0.75) for _ in range(20)], 10) / 20
     qh, th = d_q.cpu().numpy(), d_t.cpu().numpy()
     c0 = time.perf_counter(); ridx, rdist = orc.knn(qh, th, 2, threads=THREADS); cs = time.perf_counter() - c0
+    d_q16, d_t16 = gpu_rand_descriptors(160000, 21), gpu_rand_descriptors(160000, 22)
+    o16 = np.arange(17) * 10000
+    s16 = timed(lambda: D2.knn_frames(d_q16, o16, d_t16, o16, 2, ratio=0.75), 10)
     out.append({"config": "C2 10k x 10k kNN k=2 + ratio, one call", "gpu_us": s * 1e6, "gpu_evals_per_s": 1e8 / s,
+                "gpu_16_frames_one_launch_evals_per_s": 16e8 / s16,
                 "cpu_evals_per_s": 1e8 / cs, "cpu": f"oracle, {THREADS} threads",
                 "bit_exact": bool(np.array_equal(d_i.cpu().numpy(), ridx) and np.array_equal(d_d.cpu().numpy(), rdist))})
 
