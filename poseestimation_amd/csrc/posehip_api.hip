@@ -133,6 +133,7 @@ struct Context {
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
     hipEvent_t scratch_ev = nullptr;
+    RansacOverlap pnp_overlap = {nullptr, nullptr, nullptr}; // side stream of batched RANSAC
     bool profiling = false;                 // record events around the distance kernel
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -528,6 +529,9 @@ ph_status ph_init(int device)
                     device, prop.gcnArchName);
     g_ctx.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     PH_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    PH_HIP(hipStreamCreateWithFlags(&g_ctx.pnp_overlap.side, hipStreamNonBlocking));
+    PH_HIP(hipEventCreateWithFlags(&g_ctx.pnp_overlap.solved, hipEventDisableTiming));
+    PH_HIP(hipEventCreateWithFlags(&g_ctx.pnp_overlap.scored, hipEventDisableTiming));
     g_ctx.device = device;
     g_ctx.ready = true;
     return PH_OK;
@@ -555,6 +559,12 @@ void ph_shutdown(void)
     if (g_ctx.scratch_ev)
         (void)hipEventDestroy(g_ctx.scratch_ev);
     (void)hipStreamDestroy(g_ctx.stream);
+    if (g_ctx.pnp_overlap.side)
+        (void)hipStreamDestroy(g_ctx.pnp_overlap.side);
+    if (g_ctx.pnp_overlap.solved)
+        (void)hipEventDestroy(g_ctx.pnp_overlap.solved);
+    if (g_ctx.pnp_overlap.scored)
+        (void)hipEventDestroy(g_ctx.pnp_overlap.scored);
     for (hipEvent_t e : g_ctx.ev)
         if (e)
             (void)hipEventDestroy(e);
@@ -909,7 +919,7 @@ ph_status ph_ransac_epnp_hypotheses_dev(const float *d_obj, const float *d_img, 
     const double thr = reproj_err;
     PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, camera_of(K), d_subsets, nullptr, nullptr, 1,
                                     n_hyp, (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
-                                    pick_stream(stream)));
+                                    pick_stream(stream), &g_ctx.pnp_overlap));
     return PH_OK;
 }
 
@@ -937,7 +947,7 @@ ph_status ph_ransac_epnp_hypotheses_batched_dev(const float *d_obj, const float 
     PH_HIP(ransac_hypotheses_launch(d_obj, d_img, 0, camera_of(K), d_subsets, d_point_offsets,
                                     d_point_offsets + 1, n_problems, hyp_per_problem,
                                     (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
-                                    pick_stream(stream)));
+                                    pick_stream(stream), &g_ctx.pnp_overlap));
     return PH_OK;
 }
 

@@ -14,11 +14,17 @@ struct CameraK {
 // rows -> d_counts[h].  Problem p owns rows [d_begins[p], d_ends[p]) (for n_problems + 1
 // ascending offsets pass d_ends = d_begins + 1); d_begins == nullptr means one problem over
 // rows 0..n.  thr2 = (float)(reprojectionError^2).
+// overlap (optional): a second stream and two events with which the scoring of one
+// GPU-full of hypotheses runs underneath the next one's solves.
+struct RansacOverlap {
+    hipStream_t side;
+    hipEvent_t solved, scored;
+};
 hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int n, CameraK K,
                                     const int32_t *d_subsets, const int32_t *d_begins,
                                     const int32_t *d_ends, int n_problems, int hyp_per_problem,
                                     float thr2, double *d_models, int32_t *d_counts, int n_cus,
-                                    hipStream_t stream);
+                                    hipStream_t stream, const RansacOverlap *overlap = nullptr);
 
 // One byte per row: 1 iff the row is an inlier of d_model (rvec|tvec).
 hipError_t inlier_mask_launch(const float *d_obj, const float *d_img, int n, CameraK K,

@@ -1105,12 +1105,12 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(const float *__restric
                                                           const float *__restrict__ img, CameraK K,
                                                           const int32_t *__restrict__ subsets,
                                                           const int32_t *__restrict__ begins,
-                                                          int hyp_per_problem, int n_hyp,
+                                                          int hyp_per_problem, int h0, int n_hyp,
                                                           double *__restrict__ models)
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    const int h = blockIdx.x * HPW + lane;
+    const int h = h0 + blockIdx.x * HPW + lane;
     if (lane >= HPW || h >= n_hyp)
         return;
     const EpnpLds<HPW> S(lds + lane);
@@ -1133,11 +1133,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restri
                                                            const double *__restrict__ models,
                                                            const int32_t *__restrict__ begins,
                                                            const int32_t *__restrict__ ends,
-                                                           int hyp_per_problem, int n_hyp,
+                                                           int hyp_per_problem, int h0, int n_hyp,
                                                            float thr2, int32_t *__restrict__ counts)
 {
     const int lane = threadIdx.x & 63;
-    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int h = h0 + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= n_hyp)
         return;
     if (begins) {
@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(64) void epnp_solve_batched_kernel(
 template <int HPW>
 static hipError_t launch_solve(const float *d_obj, const float *d_img, CameraK K,
                                const int32_t *d_subsets, const int32_t *d_begins,
-                               int hyp_per_problem, int n_hyp, double *d_models,
+                               int hyp_per_problem, int h0, int n_hyp, double *d_models,
                                hipStream_t stream)
 {
     const size_t lds_bytes = (size_t)HPW * LDS_DOUBLES * sizeof(double);
@@ -1267,8 +1267,8 @@ static hipError_t launch_solve(const float *d_obj, const float *d_img, CameraK K
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
         return e;
-    ransac_solve_kernel<HPW><<<(n_hyp + HPW - 1) / HPW, 64, lds_bytes, stream>>>(
-        d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, n_hyp, d_models);
+    ransac_solve_kernel<HPW><<<(n_hyp - h0 + HPW - 1) / HPW, 64, lds_bytes, stream>>>(
+        d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, n_hyp, d_models);
     return hipGetLastError();
 }
 
@@ -1276,7 +1276,7 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
                                     const int32_t *d_subsets, const int32_t *d_begins,
                                     const int32_t *d_ends, int n_problems, int hyp_per_problem,
                                     float thr2, double *d_models, int32_t *d_counts, int n_cus,
-                                    hipStream_t stream)
+                                    hipStream_t stream, const RansacOverlap *overlap)
 {
     const int64_t total = (int64_t)n_problems * hyp_per_problem;
     if (total <= 0)
@@ -1288,19 +1288,45 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     // LDS capacity (1248 B per hypothesis -> 128 per CU) sets how many hypotheses are
     // in flight, so few hypotheses go 16 to a wave (as many CUs and SIMDs as
     // possible) and many go 32 to a wave (4 workgroups per CU, one per SIMD).
+    const bool small = n_hyp <= n_cus * 4 * 16;
+    // A large batch goes down in rounds of one GPU-full of solves; the scoring of a
+    // round runs on a second stream underneath the next round's solves (the solve
+    // kernel leaves most of every SIMD's issue slots and registers for one more wave).
+    const int round = n_cus * 128;
+    const bool split = overlap && !small && n_hyp > round;
     hipError_t e;
-    if (n_hyp <= n_cus * 4 * 16)
-        e = launch_solve<16>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, n_hyp,
-                             d_models, stream);
-    else
-        e = launch_solve<32>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, n_hyp,
-                             d_models, stream);
-    if (e != hipSuccess)
-        return e;
-    ransac_score_kernel<<<(n_hyp + 3) / 4, 256, 0, stream>>>(d_obj, d_img, n, K, d_models,
-                                                             d_begins, d_ends, hyp_per_problem,
-                                                             n_hyp, thr2, d_counts);
-    return hipGetLastError();
+    for (int h0 = 0; h0 < n_hyp; h0 += split ? round : n_hyp) {
+        const int h1 = split ? (n_hyp - h0 > round ? h0 + round : n_hyp) : n_hyp;
+        if (small)
+            e = launch_solve<16>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
+                                 d_models, stream);
+        else
+            e = launch_solve<32>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
+                                 d_models, stream);
+        if (e != hipSuccess)
+            return e;
+        const bool last = h1 == n_hyp;
+        hipStream_t ss = stream;
+        if (split && !last) {
+            if ((e = hipEventRecord(overlap->solved, stream)) != hipSuccess)
+                return e;
+            if ((e = hipStreamWaitEvent(overlap->side, overlap->solved, 0)) != hipSuccess)
+                return e;
+            ss = overlap->side;
+        }
+        ransac_score_kernel<<<(h1 - h0 + 3) / 4, 256, 0, ss>>>(d_obj, d_img, n, K, d_models,
+                                                               d_begins, d_ends, hyp_per_problem,
+                                                               h0, h1, thr2, d_counts);
+        if ((e = hipGetLastError()) != hipSuccess)
+            return e;
+    }
+    if (split) { // the caller's stream continues only after the side stream's scoring
+        if ((e = hipEventRecord(overlap->scored, overlap->side)) != hipSuccess)
+            return e;
+        if ((e = hipStreamWaitEvent(stream, overlap->scored, 0)) != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t inlier_mask_launch(const float *d_obj, const float *d_img, int n, CameraK K,

@@ -286,3 +286,23 @@ def test_batched_solvepnp_ransac_invalid_arguments(posehip):
                                              out.ctypes.data_as(dp), i4.ctypes.data_as(ip),
                                              i4.ctypes.data_as(ip), i4.ctypes.data_as(ip), None)
     assert st == 1   # confidence outside (0, 1)
+
+
+def test_hypotheses_beyond_one_gpu_full_equal_separate_calls(posehip):
+    """More hypotheses than one round of solves (256 CUs x 128): the call splits into
+    rounds and scores them on a second stream; every model and count must equal what
+    two smaller calls (one round each, no second stream) produce, and a sample must
+    equal the oracle."""
+    H = 40000
+    obj, img, R, t, _ = datagen.pnp_scene(n=300, outlier_frac=0.3, seed=31)
+    sub = orc.ransac_subsets(300, H)
+    for _ in range(2):   # twice: the second stream and its events are reused across calls
+        m_all, c_all = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, sub)
+    m_a, c_a = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, sub[:20000])
+    m_b, c_b = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, sub[20000:])
+    assert np.array_equal(c_all, np.concatenate([c_a, c_b]))
+    assert np.array_equal(m_all, np.concatenate([m_a, m_b]))
+    pick = np.r_[0:64, 32760:32776, 39936:40000]
+    rm, rc = orc.pnp_hypotheses(obj, img, datagen.CAMERA_K, sub[pick], threads=8)
+    assert np.array_equal(c_all[pick], rc)
+    assert np.abs(m_all[pick] - rm).max() < 1e-12

@@ -38,13 +38,13 @@ int main(int argc, char **argv)
         const int hpw = atoi(argv[2]);
         for (int r = 0; r < 3; r++) {
             CK(hipEventRecord(e0));
-            if (hpw == 1) CK(launch_solve<1>(d_obj, d_img, K, d_sub, nullptr, H, H, d_models, 0));
-            else if (hpw == 2) CK(launch_solve<2>(d_obj, d_img, K, d_sub, nullptr, H, H, d_models, 0));
-            else if (hpw == 4) CK(launch_solve<4>(d_obj, d_img, K, d_sub, nullptr, H, H, d_models, 0));
-            else if (hpw == 8) CK(launch_solve<8>(d_obj, d_img, K, d_sub, nullptr, H, H, d_models, 0));
-            else if (hpw == 16) CK(launch_solve<16>(d_obj, d_img, K, d_sub, nullptr, H, H, d_models, 0));
-            else if (hpw == 32) CK(launch_solve<32>(d_obj, d_img, K, d_sub, nullptr, H, H, d_models, 0));
-            else CK(launch_solve<64>(d_obj, d_img, K, d_sub, nullptr, H, H, d_models, 0));
+            if (hpw == 1) CK(launch_solve<1>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0));
+            else if (hpw == 2) CK(launch_solve<2>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0));
+            else if (hpw == 4) CK(launch_solve<4>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0));
+            else if (hpw == 8) CK(launch_solve<8>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0));
+            else if (hpw == 16) CK(launch_solve<16>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0));
+            else if (hpw == 32) CK(launch_solve<32>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0));
+            else CK(launch_solve<64>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0));
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf("H=%d HPW=%d solve only: %.3f ms -> %.3g hyps/s\n", H, hpw, ms, H / (ms * 1e-3));
