@@ -37,12 +37,15 @@ hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const v
 // arrays of n_frames + 1 ascending offsets).  Outputs are indexed by query row over
 // the whole batch; train indices are local to the frame.  max_nq / max_nt bound
 // the frames' sizes (the launch grid and the split count come from them).
+// uniform_frames: all frames hold the same numbers of rows (enables the XCD-contiguous
+// workgroup order, see the kernel).
 KnnPlan knn_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int64_t total_nq, int n_cus);
 hipError_t knn_frames_launch(const KnnPlan &p, const void *d_query, const int32_t *d_q_off,
                              const void *d_train, const int32_t *d_t_off, int n_frames,
                              int64_t total_nq, int k, uint32_t *d_part, int32_t *d_out_idx,
                              int32_t *d_out_dist, uint8_t *d_keep, float ratio,
-                             hipStream_t stream, hipEvent_t *events = nullptr);
+                             hipStream_t stream, hipEvent_t *events = nullptr,
+                             bool uniform_frames = false);
 
 // Train rows per split of a frame with nt train rows under plan p.
 int64_t frame_rows_per_split(int64_t nt, const KnnPlan &p);

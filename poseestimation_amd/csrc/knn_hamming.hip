@@ -180,14 +180,15 @@ __device__ __forceinline__ void knn_partial_body(const uint4 *__restrict__ query
                                                  const uint4 *__restrict__ train, int64_t nq,
                                                  int64_t nt, int64_t rows_per_split,
                                                  int rows_per_wave, uint32_t *__restrict__ part,
-                                                 int64_t part_row0, int64_t part_stride)
+                                                 int64_t part_row0, int64_t part_stride,
+                                                 unsigned q_block, unsigned split_id)
 {
     __shared__ uint32_t lds[2][KNN_MAX_WAVES][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_waves = blockDim.x >> 6;
-    const int64_t qi = (int64_t)blockIdx.x * 64 + lane;
-    const int split = blockIdx.y;
+    const int64_t qi = (int64_t)q_block * 64 + lane;
+    const int split = (int)split_id;
     const int64_t t0 = (int64_t)split * rows_per_split;
     const int n_split = (int)min(nt - t0, rows_per_split);
     const int w0 = wave * rows_per_wave;
@@ -248,7 +249,8 @@ __global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_kernel(
     const uint4 *__restrict__ query, const uint4 *__restrict__ train, int64_t nq, int64_t nt,
     int64_t rows_per_split, int rows_per_wave, uint32_t *__restrict__ part)
 {
-    knn_partial_body<LAZY, K>(query, train, nq, nt, rows_per_split, rows_per_wave, part, 0, nq);
+    knn_partial_body<LAZY, K>(query, train, nq, nt, rows_per_split, rows_per_wave, part, 0, nq,
+                              blockIdx.x, blockIdx.y);
 }
 
 // Train rows per split / per wave of a frame in a batch of frames: every frame uses
@@ -273,20 +275,37 @@ __host__ __device__ inline FrameGeom frame_geom(int64_t nt, int n_splits, int wa
 // A batch of independent matching problems ("frames") in one launch: frame
 // f = blockIdx.z matches query rows [q_off[f], q_off[f+1]) against train rows
 // [t_off[f], t_off[f+1]).  Workgroups beyond a frame's own query blocks leave at once.
+//
+// xcd_chunks: workgroups are dealt round-robin over the 8 XCDs (linear id mod 8), each
+// with its own L2.  With the flag set the linear id is remapped so that every XCD works
+// through one contiguous eighth of the (frame, split, query block) space, i.e. whole
+// frames: each frame's descriptors are then pulled into one L2 instead of all eight.
+// The host sets it for batches of equally sized frames only (contiguous eighths of a
+// ragged batch would not hold equal work).
 template <bool LAZY, int K>
 __global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_frames_kernel(
     const uint4 *__restrict__ query, const uint4 *__restrict__ train,
     const int32_t *__restrict__ q_off, const int32_t *__restrict__ t_off, int64_t total_nq,
-    uint32_t *__restrict__ part)
+    uint32_t *__restrict__ part, int xcd_chunks)
 {
-    const int f = blockIdx.z;
+    unsigned bx = blockIdx.x, by = blockIdx.y, f = blockIdx.z;
+    if (xcd_chunks) {
+        const unsigned X = gridDim.x, Y = gridDim.y, N = X * Y * gridDim.z;
+        const unsigned L = bx + X * (by + Y * f);
+        const unsigned base = N >> 3, rem = N & 7, c = L & 7;
+        const unsigned nl = c * base + min(c, rem) + (L >> 3); // bijective for any N
+        bx = nl % X;
+        const unsigned t = nl / X;
+        by = t % Y;
+        f = t / Y;
+    }
     const int64_t q0 = q_off[f], nq = q_off[f + 1] - q0;
     const int64_t t0 = t_off[f], nt = t_off[f + 1] - t0;
-    if ((int64_t)blockIdx.x * 64 >= nq)
+    if ((int64_t)bx * 64 >= nq)
         return;
     const FrameGeom g = frame_geom(nt, (int)gridDim.y, (int)(blockDim.x >> 6));
     knn_partial_body<LAZY, K>(query + 2 * q0, train + 2 * t0, nq, nt, g.rows_per_split,
-                              g.rows_per_wave, part, q0, total_nq);
+                              g.rows_per_wave, part, q0, total_nq, bx, by);
 }
 
 // Folds the per-split keys into the final k-NN rows.  Keys become
@@ -601,8 +620,9 @@ hipError_t knn_frames_launch(const KnnPlan &p, const void *d_query, const int32_
                              const void *d_train, const int32_t *d_t_off, int n_frames,
                              int64_t total_nq, int k, uint32_t *d_part, int32_t *d_out_idx,
                              int32_t *d_out_dist, uint8_t *d_keep, float ratio,
-                             hipStream_t stream, hipEvent_t *events)
+                             hipStream_t stream, hipEvent_t *events, bool uniform_frames)
 {
+    const int xcd = uniform_frames && n_frames >= 8 ? 1 : 0;
     if (p.waves < 1 || p.waves > KNN_MAX_WAVES || p.n_splits < 1 || p.n_splits > 65535 ||
         n_frames < 1 || n_frames > 65535 || p.q_blocks < 1)
         return hipErrorInvalidValue;
@@ -614,16 +634,16 @@ hipError_t knn_frames_launch(const KnnPlan &p, const void *d_query, const int32_
     const int threads = p.waves * 64;
     if (p.lazy && k == 2)
         knn_partial_frames_kernel<true, 2><<<grid, threads, 0, stream>>>(q4, t4, d_q_off, d_t_off,
-                                                                         total_nq, d_part);
+                                                                         total_nq, d_part, xcd);
     else if (p.lazy)
         knn_partial_frames_kernel<true, 1><<<grid, threads, 0, stream>>>(q4, t4, d_q_off, d_t_off,
-                                                                         total_nq, d_part);
+                                                                         total_nq, d_part, xcd);
     else if (k == 2)
         knn_partial_frames_kernel<false, 2><<<grid, threads, 0, stream>>>(q4, t4, d_q_off, d_t_off,
-                                                                          total_nq, d_part);
+                                                                          total_nq, d_part, xcd);
     else
         knn_partial_frames_kernel<false, 1><<<grid, threads, 0, stream>>>(q4, t4, d_q_off, d_t_off,
-                                                                          total_nq, d_part);
+                                                                          total_nq, d_part, xcd);
     if ((e = hipGetLastError()) != hipSuccess)
         return e;
     if (events && (e = hipEventRecord(events[1], stream)) != hipSuccess)

@@ -346,6 +346,7 @@ ph_status check_host_args(const uint8_t *q, int nq, size_t q_step, const uint8_t
 // ---- batches of frames -----------------------------------------------------------
 struct FrameBatch {
     int64_t max_nq = 0, max_nt = 0;
+    bool uniform = true; // every frame has max_nq query rows and max_nt train rows
     int64_t q_begin = 0, q_end = 0, t_end = 0;
     const int32_t *d_q_off = nullptr, *d_t_off = nullptr; // device copies of the tables
 };
@@ -369,6 +370,9 @@ ph_status check_frames(const int32_t *q_offsets, const int32_t *t_offsets, int n
         fb.max_nq = std::max(fb.max_nq, a);
         fb.max_nt = std::max(fb.max_nt, b);
     }
+    for (int f = 0; f < n_frames; f++)
+        if (q_offsets[f + 1] - q_offsets[f] != fb.max_nq || t_offsets[f + 1] - t_offsets[f] != fb.max_nt)
+            fb.uniform = false;
     fb.q_begin = q_offsets[0];
     fb.q_end = q_offsets[n_frames];
     fb.t_end = t_offsets[n_frames];
@@ -711,7 +715,7 @@ ph_status ph_knn_hamming256_frames_dev(const void *d_query, const int32_t *q_off
     hipEvent_t *ev = g_ctx.profiling ? g_ctx.ev : nullptr;
     PH_HIP(knn_frames_launch(plan, d_query, fb.d_q_off, d_train, fb.d_t_off, n_frames, fb.q_end, k,
                              (uint32_t *)g_ctx.part.p, d_out_idx, d_out_dist, d_keep, ratio, st,
-                             ev));
+                             ev, fb.uniform));
     PH_HIP(hipEventRecord(slot->done, st));
     g_ctx.ev_valid = ev != nullptr;
     return PH_OK;
@@ -760,7 +764,7 @@ ph_status ph_match_crosscheck_hamming256_frames_dev(const void *d_query, const i
         return s;
     PH_HIP(knn_frames_launch(plan, d_train, fb.d_t_off, d_query, fb.d_q_off, n_frames, fb.t_end, 1,
                              (uint32_t *)g_ctx.part2.p, (int32_t *)g_ctx.tmp_i.p,
-                             (int32_t *)g_ctx.tmp_d.p, nullptr, 0.f, st, nullptr));
+                             (int32_t *)g_ctx.tmp_d.p, nullptr, 0.f, st, nullptr, fb.uniform));
     PH_HIP(crosscheck_resolve_frames_launch((const int32_t *)g_ctx.tmp_i.p,
                                             (const int32_t *)g_ctx.tmp_d.p, fb.d_q_off, fb.d_t_off,
                                             n_frames, fb.max_nt, fb.q_begin, fb.q_end,
