@@ -59,8 +59,20 @@ def _u8(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint8))
 
 
+_DM_DTYPE = np.dtype([("q", "<i4"), ("t", "<i4"), ("i", "<i4"), ("d", "<f4")])
+
+
+def _dm(q, t, i, d):
+    m = object.__new__(DMatch)  # the values are Python ints / floats already
+    m.queryIdx, m.trainIdx, m.imgIdx, m.distance = q, t, i, d
+    return m
+
+
 def _dm_list(buf, n):
-    return [DMatch(m.queryIdx, m.trainIdx, m.imgIdx, m.distance) for m in buf[:n]]
+    if n == 0:
+        return []
+    a = np.frombuffer(buf, dtype=_DM_DTYPE, count=n)
+    return list(map(_dm, a["q"].tolist(), a["t"].tolist(), a["i"].tolist(), a["d"].tolist()))
 
 
 class BFMatcher:
