@@ -622,7 +622,10 @@ hipError_t knn_frames_launch(const KnnPlan &p, const void *d_query, const int32_
                              int32_t *d_out_dist, uint8_t *d_keep, float ratio,
                              hipStream_t stream, hipEvent_t *events, bool uniform_frames)
 {
-    const int xcd = uniform_frames && n_frames >= 8 ? 1 : 0;
+    // (the remap works on 32-bit linear workgroup ids)
+    const int xcd = uniform_frames && n_frames >= 8 &&
+                            (uint64_t)p.q_blocks * (uint64_t)p.n_splits * (uint64_t)n_frames < (1ull << 31)
+                        ? 1 : 0;
     if (p.waves < 1 || p.waves > KNN_MAX_WAVES || p.n_splits < 1 || p.n_splits > 65535 ||
         n_frames < 1 || n_frames > 65535 || p.q_blocks < 1)
         return hipErrorInvalidValue;

@@ -548,3 +548,27 @@ def test_crosscheck_frames(posehip, tie_stress):
                 want_i[qi], want_d[qi] = ti, int(d)
         assert np.array_equal(idx[qo[f]:qo[f + 1]], want_i), f
         assert np.array_equal(dist[qo[f]:qo[f + 1]], want_d), f
+
+
+@pytest.mark.parametrize("F,nq,nt", [(8, 700, 900), (9, 129, 2051), (19, 64, 64)])
+def test_frames_uniform_batches(posehip, F, nq, nt):
+    """Eight or more equally sized frames take the XCD-contiguous workgroup order
+    (also with workgroup counts that are not multiples of 8): every frame against the
+    oracle, k = 2 + ratio and the cross-check."""
+    import torch
+    from poseestimation_amd import distributed as D
+    q = datagen.codebook_descriptors(F * nq, 91, words=512)
+    t = datagen.codebook_descriptors(F * nt, 92, words=512)
+    qo, to = np.arange(F + 1) * nq, np.arange(F + 1) * nt
+    with torch.cuda.stream(torch.cuda.Stream()):
+        idx, dist, keep = D.knn_frames(_dev(q), qo, _dev(t), to, 2, ratio=0.8)
+        cidx, cdist = D.match_crosscheck_frames(_dev(q), qo, _dev(t), to)
+        torch.cuda.current_stream().synchronize()
+    ridx, rdist = _frames_reference(q, qo, t, to, 2)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dist.cpu().numpy(), rdist)
+    cidx, cdist = cidx.cpu().numpy(), cdist.cpu().numpy()
+    for f in range(F):
+        want = np.full(nq, -1, np.int32)
+        for qi, ti, _, d in orc.match(q[qo[f]:qo[f + 1]], t[to[f]:to[f + 1]], cross_check=True):
+            want[qi] = ti
+        assert np.array_equal(cidx[qo[f]:qo[f + 1]], want), f
