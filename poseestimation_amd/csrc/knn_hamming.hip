@@ -249,8 +249,16 @@ __global__ __launch_bounds__(KNN_MAX_WAVES * 64) void knn_partial_kernel(
     const uint4 *__restrict__ query, const uint4 *__restrict__ train, int64_t nq, int64_t nt,
     int64_t rows_per_split, int rows_per_wave, uint32_t *__restrict__ part)
 {
+    // Workgroups are dealt round-robin over the 8 XCDs (linear id mod 8), each with its
+    // own L2: remap the linear id so that every XCD works through one contiguous eighth
+    // of the (split, query block) space -- a band of train splits -- instead of touching
+    // every train row from every L2.  Bijective for any grid size.
+    const unsigned X = gridDim.x, N = X * gridDim.y;
+    const unsigned L = blockIdx.x + X * blockIdx.y;
+    const unsigned base = N >> 3, rem = N & 7, c = L & 7;
+    const unsigned nl = c * base + min(c, rem) + (L >> 3);
     knn_partial_body<LAZY, K>(query, train, nq, nt, rows_per_split, rows_per_wave, part, 0, nq,
-                              blockIdx.x, blockIdx.y);
+                              nl % X, nl / X);
 }
 
 // Train rows per split / per wave of a frame in a batch of frames: every frame uses
