@@ -129,6 +129,8 @@ struct Context {
     };
     OffsetSlot off_ring[4];
     int off_next = 0;
+    int off_cached = -1; // slot whose tables equal the last call's (re-used without a copy)
+    int off_cached_frames = 0;
     // The workspace above is shared by all calls: the stream that used it last.
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
@@ -384,7 +386,22 @@ ph_status check_frames(const int32_t *q_offsets, const int32_t *t_offsets, int n
 ph_status upload_frame_tables(const int32_t *q_offsets, const int32_t *t_offsets, int n_frames,
                               hipStream_t st, FrameBatch &fb, Context::OffsetSlot *&slot)
 {
+    const size_t tab_bytes = (size_t)(n_frames + 1) * sizeof(int32_t);
+    if (g_ctx.off_cached >= 0 && g_ctx.off_cached_frames == n_frames) {
+        // the same batch layout as the last call (a steady stream of equal batches): the
+        // device copy is still valid and later work on it is ordered by the stream
+        Context::OffsetSlot &c = g_ctx.off_ring[g_ctx.off_cached];
+        if (memcmp(c.h.p, q_offsets, tab_bytes) == 0 &&
+            memcmp((const uint8_t *)c.h.p + tab_bytes, t_offsets, tab_bytes) == 0) {
+            slot = &c;
+            fb.d_q_off = (const int32_t *)c.d.p;
+            fb.d_t_off = fb.d_q_off + (n_frames + 1);
+            return PH_OK;
+        }
+    }
+    g_ctx.off_cached = -1;
     slot = &g_ctx.off_ring[g_ctx.off_next];
+    const int slot_index = g_ctx.off_next;
     g_ctx.off_next = (g_ctx.off_next + 1) % 4;
     if (!slot->done)
         PH_HIP(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
@@ -398,6 +415,8 @@ ph_status upload_frame_tables(const int32_t *q_offsets, const int32_t *t_offsets
     PH_HIP(hipMemcpyAsync(slot->d.p, slot->h.p, 2 * tab, hipMemcpyHostToDevice, st));
     fb.d_q_off = (const int32_t *)slot->d.p;
     fb.d_t_off = fb.d_q_off + (n_frames + 1);
+    g_ctx.off_cached = slot_index;
+    g_ctx.off_cached_frames = n_frames;
     return PH_OK;
 }
 
