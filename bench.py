@@ -310,6 +310,8 @@ def main():
                     "what": f"the same {F} frames, one ph_knn_hamming256_dev call per frame, rank 0"}
         roofline = {
             "bound": "valu",
+            "bound_note": "integer VALU issue (xor + popcount): the path is neither HBM- nor "
+                          "MFMA-bound; hbm_algorithmic_GBps and traffic show how far it is from HBM",
             "kernel": "knn_partial_frames_kernel",
             "achieved": achieved / 1e12,
             "peak": peak_evals / 1e12,
