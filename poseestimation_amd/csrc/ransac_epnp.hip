@@ -105,6 +105,25 @@ __device__ double hypot_cr(double x, double y)
     return hypot_kernel(ax, ay);
 }
 
+// Rotation (c, s) of a Jacobi pair:
+//   beta < 0:  delta = (gamma - beta) * 0.5;  s = sqrt(delta / gamma);  c = p / (gamma * s * 2)
+//   else:      c = sqrt((gamma + beta) / (gamma * 2));                  s = p / (gamma * c * 2)
+// written with selects around ONE square root and two divisions: the lanes of a wave
+// split about evenly on the sign of beta, and as a branch both sides (a square root and
+// two divisions each) would be issued for every rotation.  Each lane performs exactly
+// the operations of its own case, so the results are unchanged.
+__device__ __forceinline__ void jacobi_rotation(double p, double beta, double gamma, double &c,
+                                                double &s)
+{
+    const bool neg = beta < 0;
+    const double num = neg ? (gamma - beta) * 0.5 : gamma + beta;
+    const double den = neg ? gamma : gamma * 2;
+    const double r = sqrt(num / den);
+    const double o = p / (gamma * r * 2);
+    c = neg ? o : r;
+    s = neg ? r : o;
+}
+
 // Pointer into a lane's interleaved LDS arrays: consecutive elements of one
 // lane are ST words apart (ST = hypotheses per workgroup).
 template <int ST> struct LP {
@@ -160,14 +179,7 @@ __device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep,
                     continue;
                 p *= 2;
                 const double beta = a - b, gamma = hypot_cr(p, beta);
-                if (beta < 0) {
-                    const double delta = (gamma - beta) * 0.5;
-                    s = sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
-                }
+                jacobi_rotation(p, beta, gamma, c, s);
                 a = b = 0;
                 for (int k = 0; k < m; k++) {
                     const double t0 = c * Ai[k] + s * Aj[k];
@@ -299,14 +311,7 @@ template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
                 p *= 2;
                 const double beta = a - b, gamma = hypot_cr(p, beta);
                 double c, s;
-                if (beta < 0) {
-                    const double delta = (gamma - beta) * 0.5;
-                    s = sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
-                }
+                jacobi_rotation(p, beta, gamma, c, s);
                 a = b = 0;
 #pragma unroll
                 for (int k = 0; k < N; k++) {
