@@ -306,3 +306,23 @@ def test_hypotheses_beyond_one_gpu_full_equal_separate_calls(posehip):
     rm, rc = orc.pnp_hypotheses(obj, img, datagen.CAMERA_K, sub[pick], threads=8)
     assert np.array_equal(c_all[pick], rc)
     assert np.abs(m_all[pick] - rm).max() < 1e-12
+
+
+def test_degenerate_samples_agree_with_oracle(posehip):
+    """Collinear, coincident and all-zero correspondences: the solve must terminate (its
+    Jacobi sweeps and zero-row completion are bounded) and give the oracle's counts; models
+    are compared where the oracle's are finite (NaN stays NaN)."""
+    rng = np.random.default_rng(41)
+    n = 64
+    line = np.outer(np.linspace(-1, 1, n), [1.0, 0.5, 0.2]).astype(np.float32)
+    same = np.tile(np.array([[0.3, -0.2, 0.1]], np.float32), (n, 1))
+    zero = np.zeros((n, 3), np.float32)
+    img = (rng.random((n, 2)) * [800, 600]).astype(np.float32)
+    sub = orc.ransac_subsets(n, 32)
+    for obj in (line, same, zero):
+        m, c = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, sub)
+        rm, rc = orc.pnp_hypotheses(obj, img, datagen.CAMERA_K, sub)
+        assert np.array_equal(c, rc)
+        assert np.array_equal(np.isnan(m), np.isnan(rm))
+        fin = np.isfinite(rm)
+        assert np.allclose(m[fin], rm[fin], rtol=1e-9, atol=1e-9)
