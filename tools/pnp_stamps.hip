@@ -34,6 +34,28 @@ int main(int argc, char **argv)
     CK(hipMemcpy(d_sub, sub.data(), sub.size() * 4, hipMemcpyHostToDevice));
     CameraK K{f, f, 400, 300};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (argc > 3) { // H HPW LDS_KB: solve kernel only, workgroup LDS padded to LDS_KB (spreads the waves)
+        const int hpw = atoi(argv[2]);
+        const size_t lds = (size_t)atoi(argv[3]) * 1024;
+        for (int r = 0; r < 3; r++) {
+            CK(hipEventRecord(e0));
+            if (hpw == 4) {
+                CK(hipFuncSetAttribute((const void *)ransac_solve_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ransac_solve_kernel<4><<<(H + 3) / 4, 64, lds, 0>>>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models);
+            } else if (hpw == 8) {
+                CK(hipFuncSetAttribute((const void *)ransac_solve_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ransac_solve_kernel<8><<<(H + 7) / 8, 64, lds, 0>>>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models);
+            } else {
+                CK(hipFuncSetAttribute((const void *)ransac_solve_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ransac_solve_kernel<16><<<(H + 15) / 16, 64, lds, 0>>>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models);
+            }
+            CK(hipGetLastError());
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("H=%d HPW=%d LDS=%zu KB solve only: %.3f ms -> %.3g hyps/s\n", H, hpw, lds / 1024, ms, H / (ms * 1e-3));
+        }
+        return 0;
+    }
     if (argc > 2) { // force hypotheses per workgroup: solve kernel only
         const int hpw = atoi(argv[2]);
         for (int r = 0; r < 3; r++) {
