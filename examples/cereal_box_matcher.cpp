@@ -61,6 +61,20 @@ int main()
     std::vector<DMatch> ratio;
     ratioTestMatch(Descriptors(descriptors.data(), n_new), Descriptors(descriptorsOld.data(), n_old), 0.75f, ratio);
 
+    // the train set resident on the GPU (add + train): the same matches as passing it per call
+    BFMatcher resident;
+    resident.add(Descriptors(descriptorsOld.data(), n_old));
+    resident.train();
+    std::vector<DMatch> matches_resident;
+    resident.match(Descriptors(descriptors.data(), n_new), matches_resident);
+    bool resident_same = matches_resident.size() == matches.size();
+    for (std::size_t i = 0; resident_same && i < matches.size(); i++)
+        resident_same = matches_resident[i].trainIdx == matches[i].trainIdx &&
+                        matches_resident[i].distance == matches[i].distance && matches_resident[i].imgIdx == 0;
+    std::printf("resident train set gives the same matches: %d\n", (int)resident_same);
+    if (!resident_same)
+        return 1;
+
     long long digest = 0;
     for (const DMatch &m : matches)
         digest = digest * 1000003 + m.queryIdx * 131 + m.trainIdx * 17 + (int)m.distance;

@@ -102,6 +102,33 @@ ph_status ph_knn2_ratio_hamming256(const uint8_t *query, int nq, size_t q_step,
  * elements in the reference).  out holds up to n entries; out may equal m. */
 ph_status ph_min_dist_filter(const ph_dmatch *m, int n, ph_dmatch *out, int *n_out);
 
+/* The Lowe ratio test on the rows of a k = 2 result (idx / dist as written by
+ * ph_knn_hamming256): keep row i iff it has two neighbours and
+ * (float)dist[2i] < ratio * (float)dist[2i+1].  Host-only; out holds up to nq
+ * entries.  (Defined by the benchmark configuration, not by the reference; the
+ * device entry points apply the same test on the GPU through d_keep.) */
+ph_status ph_ratio_filter(const int32_t *idx, const int32_t *dist, int nq, float ratio,
+                          ph_dmatch *out, int *n_out);
+
+/* ---- a train set resident in HBM ------------------------------------------- */
+/* DescriptorMatcher::add(descriptors) + train() of OpenCV's matcher interface
+ * (the reference passes the train set on every call, src/cereal_box.cpp:344): a
+ * model database that many frames are matched against is uploaded once.
+ * ph_db_upload copies nt rows (stride t_step >= 32) to the GPU and returns a
+ * handle; ph_db_free releases it (ph_shutdown releases all live handles);
+ * ph_db_device_ptr is the packed device buffer for the device entry points
+ * below.  ph_db_knn_hamming256 is ph_knn_hamming256 against the resident set
+ * (host queries, host results; keep may be NULL, otherwise k must be 2 and
+ * keep[i] receives the ratio test's verdict). */
+typedef struct ph_db ph_db;
+ph_status ph_db_upload(const uint8_t *train, int64_t nt, size_t t_step, ph_db **db);
+ph_status ph_db_free(ph_db *db);
+int64_t ph_db_rows(const ph_db *db);           /* -1 for a dead handle */
+const void *ph_db_device_ptr(const ph_db *db); /* NULL for a dead handle or an empty set */
+ph_status ph_db_knn_hamming256(const ph_db *db, const uint8_t *query, int64_t nq, size_t q_step,
+                               int k, int32_t *out_idx, int32_t *out_dist, uint8_t *keep,
+                               float ratio);
+
 /* ---- descriptor matching, device buffers --------------------------------- */
 
 /* Same result as ph_knn_hamming256 with HBM-resident inputs and outputs.

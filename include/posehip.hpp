@@ -132,8 +132,90 @@ class BFMatcher {
 
     bool isCrossCheck() const { return crossCheck_; }
 
+    // ---- the train collection of cv::DescriptorMatcher: add() one descriptor set per
+    // train image, train() uploads their concatenation to the GPU once, and
+    // match(query, matches) / knnMatch(query, matches, k) then send only the query.
+    void add(const Descriptors &descriptors)
+    {
+        imgStart_.push_back((int)(rows_.size() / 32));
+        for (int i = 0; i < descriptors.rows; i++)
+            rows_.insert(rows_.end(), descriptors.data + (std::size_t)i * descriptors.step,
+                         descriptors.data + (std::size_t)i * descriptors.step + 32);
+        db_.reset();
+    }
+    void clear()
+    {
+        rows_.clear();
+        imgStart_.clear();
+        db_.reset();
+    }
+    bool empty() const { return rows_.empty(); }
+    void train()
+    {
+        if (db_ && ph_db_rows(db_.get()) >= 0)
+            return;
+        ph_db *h = nullptr;
+        static const std::uint8_t none = 0;
+        check(ph_db_upload(rows_.empty() ? &none : rows_.data(), (std::int64_t)(rows_.size() / 32), 32, &h));
+        db_ = std::shared_ptr<ph_db>(h, [](ph_db *p) {
+            if (ph_db_rows(p) >= 0) // not already released by ph_shutdown
+                ph_db_free(p);
+        });
+    }
+    void knnMatch(const Descriptors &query, std::vector<std::vector<DMatch>> &matches, int k)
+    {
+        matches.clear();
+        if (k != 1 && k != 2)
+            throw Error(PH_ERR_INVALID_ARG, "k must be 1 or 2");
+        if (crossCheck_) { // needs the swapped search too: one call on the concatenation
+            if (k != 1)
+                throw Error(PH_ERR_INVALID_ARG, "crossCheck requires k == 1");
+            std::vector<DMatch> flat;
+            match(query, Descriptors(rows_.data(), (int)(rows_.size() / 32), 32), flat);
+            for (DMatch &m : flat) {
+                localise(m);
+                matches.push_back({m});
+            }
+            return;
+        }
+        if (query.rows == 0 || rows_.empty())
+            return;
+        train();
+        std::vector<std::int32_t> idx((std::size_t)query.rows * k), dist((std::size_t)query.rows * k);
+        check(ph_db_knn_hamming256(db_.get(), query.data, query.rows, query.step, k, idx.data(), dist.data(),
+                                   nullptr, 0.f));
+        matches.resize((std::size_t)query.rows);
+        for (int i = 0; i < query.rows; i++)
+            for (int r = 0; r < k && idx[(std::size_t)i * k + r] >= 0; r++) {
+                DMatch m(i, idx[(std::size_t)i * k + r], 0, (float)dist[(std::size_t)i * k + r]);
+                localise(m);
+                matches[(std::size_t)i].push_back(m);
+            }
+    }
+    void match(const Descriptors &query, std::vector<DMatch> &matches)
+    {
+        std::vector<std::vector<DMatch>> rows;
+        knnMatch(query, rows, 1);
+        matches.clear();
+        for (const auto &r : rows)
+            if (!r.empty())
+                matches.push_back(r[0]);
+    }
+
   private:
+    // index into the concatenation -> (imgIdx, index within that image)
+    void localise(DMatch &m) const
+    {
+        int img = 0;
+        while (img + 1 < (int)imgStart_.size() && imgStart_[(std::size_t)img + 1] <= m.trainIdx)
+            img++;
+        m.imgIdx = img;
+        m.trainIdx -= imgStart_.empty() ? 0 : imgStart_[(std::size_t)img];
+    }
     bool crossCheck_;
+    std::vector<std::uint8_t> rows_; // the added descriptor sets, packed
+    std::vector<int> imgStart_;      // first row of every train image
+    std::shared_ptr<ph_db> db_;      // their resident copy
 };
 
 // DescriptorMatcher::create("BruteForce-Hamming"): src/cereal_box.cpp:53.

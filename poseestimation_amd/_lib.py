@@ -47,6 +47,13 @@ SIGNATURES = {
     "ph_knn2_ratio_hamming256": (C.c_int, [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int, C.c_size_t,
                                            C.c_float, _dmp, _intp]),
     "ph_min_dist_filter": (C.c_int, [_dmp, C.c_int, _dmp, _intp]),
+    "ph_ratio_filter": (C.c_int, [_i32p, _i32p, C.c_int, C.c_float, _dmp, _intp]),
+    "ph_db_upload": (C.c_int, [_u8p, C.c_int64, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ph_db_free": (C.c_int, [C.c_void_p]),
+    "ph_db_rows": (C.c_int64, [C.c_void_p]),
+    "ph_db_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "ph_db_knn_hamming256": (C.c_int, [C.c_void_p, _u8p, C.c_int64, C.c_size_t, C.c_int, _i32p,
+                                       _i32p, _u8p, C.c_float]),
     "ph_knn_hamming256_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                         C.c_void_p]),

@@ -10,11 +10,19 @@
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "knn_hamming.h"
 #include "ransac_epnp.h"
 #include "posehip.h"
+
+// A train set resident in HBM (ph_db_upload); opaque to the C ABI.
+struct ph_db {
+    void *d = nullptr;
+    int64_t rows = 0;
+    int device = -1;
+};
 
 namespace {
 
@@ -143,6 +151,8 @@ struct Context {
 
 Context g_ctx;
 std::mutex g_mu;
+std::unordered_set<ph_db *> g_dbs; // live resident train sets (freed at ph_shutdown)
+
 
 ph_status ensure_ready()
 {
@@ -267,6 +277,8 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 void pack_rows(uint8_t *dst, const uint8_t *src, int64_t n, size_t step)
 {
+    if (n <= 0)
+        return;
     if (step == 32) {
         memcpy(dst, src, (size_t)n * 32);
         return;
@@ -567,6 +579,11 @@ void ph_shutdown(void)
         return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipDeviceSynchronize(); // callers' streams may still hold work that uses the workspace
+    for (ph_db *db : g_dbs) {
+        (void)hipFree(db->d);
+        delete db;
+    }
+    g_dbs.clear();
     DevBuf *all[] = {&g_ctx.part,  &g_ctx.part2, &g_ctx.best,   &g_ctx.tmp_i,
                      &g_ctx.tmp_d, &g_ctx.d_in,  &g_ctx.pnp_idx};
     for (DevBuf *b : all)
@@ -916,6 +933,148 @@ ph_status ph_knn2_ratio_hamming256(const uint8_t *query, int nq, size_t q_step,
 {
     return host_match_list(query, nq, q_step, train, nt, t_step, MatchMode::Ratio, ratio, out,
                            n_out);
+}
+
+ph_status ph_ratio_filter(const int32_t *idx, const int32_t *dist, int nq, float ratio,
+                          ph_dmatch *out, int *n_out)
+{
+    if (!n_out)
+        return fail(PH_ERR_INVALID_ARG, "n_out is null");
+    *n_out = 0;
+    if (nq < 0 || (nq > 0 && (!idx || !dist || !out)))
+        return fail(PH_ERR_INVALID_ARG, "bad k-NN arrays");
+    int n = 0;
+    for (int i = 0; i < nq; i++) {
+        const int32_t i1 = idx[2 * (size_t)i], i2 = idx[2 * (size_t)i + 1];
+        if (i1 < 0 || i2 < 0)
+            continue; // fewer than two neighbours: nothing to compare with
+        if ((float)dist[2 * (size_t)i] < ratio * (float)dist[2 * (size_t)i + 1]) {
+            out[n].queryIdx = i;
+            out[n].trainIdx = i1;
+            out[n].imgIdx = 0;
+            out[n].distance = (float)dist[2 * (size_t)i];
+            n++;
+        }
+    }
+    *n_out = n;
+    return PH_OK;
+}
+
+ph_status ph_db_upload(const uint8_t *train, int64_t nt, size_t t_step, ph_db **db)
+{
+    if (db)
+        *db = nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (!db)
+        return fail(PH_ERR_INVALID_ARG, "db is null");
+    if ((s = check_rows(train, nt, "train")) != PH_OK)
+        return s;
+    if (nt > 0 && t_step < 32)
+        return fail(PH_ERR_INVALID_ARG, "row stride below 32 bytes");
+    ph_db *h = new ph_db();
+    h->rows = nt;
+    h->device = g_ctx.device;
+    if (nt > 0) {
+        hipError_t e = hipMalloc(&h->d, (size_t)nt * 32);
+        if (e != hipSuccess) {
+            delete h;
+            return fail(PH_ERR_HIP, "hipMalloc of %lld train rows: %s", (long long)nt,
+                        hipGetErrorString(e));
+        }
+        // rows are packed through the pinned gather buffer, 16 MiB at a time
+        const int64_t chunk_rows = (16 << 20) / 32;
+        e = g_ctx.h_in.reserve((size_t)std::min(nt, chunk_rows) * 32);
+        for (int64_t r0 = 0; e == hipSuccess && r0 < nt; r0 += chunk_rows) {
+            const int64_t m = std::min(chunk_rows, nt - r0);
+            pack_rows((uint8_t *)g_ctx.h_in.p, train + (size_t)r0 * t_step, m, t_step);
+            e = hipMemcpyAsync((uint8_t *)h->d + (size_t)r0 * 32, g_ctx.h_in.p, (size_t)m * 32,
+                               hipMemcpyHostToDevice, g_ctx.stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(g_ctx.stream); // the gather buffer is reused
+        }
+        if (e != hipSuccess) {
+            (void)hipFree(h->d);
+            delete h;
+            return fail(PH_ERR_HIP, "uploading the train set: %s", hipGetErrorString(e));
+        }
+    }
+    g_dbs.insert(h);
+    *db = h;
+    return PH_OK;
+}
+
+ph_status ph_db_free(ph_db *db)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!db)
+        return PH_OK;
+    if (!g_dbs.count(db)) // also: freed already by ph_shutdown
+        return fail(PH_ERR_INVALID_ARG, "not a live train-set handle");
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    (void)hipDeviceSynchronize(); // queued work may still read it
+    (void)hipFree(db->d);
+    g_dbs.erase(db);
+    delete db;
+    return PH_OK;
+}
+
+int64_t ph_db_rows(const ph_db *db)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return db && g_dbs.count(const_cast<ph_db *>(db)) ? db->rows : -1;
+}
+
+const void *ph_db_device_ptr(const ph_db *db)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return db && g_dbs.count(const_cast<ph_db *>(db)) ? db->d : nullptr;
+}
+
+ph_status ph_db_knn_hamming256(const ph_db *db, const uint8_t *query, int64_t nq, size_t q_step,
+                               int k, int32_t *out_idx, int32_t *out_dist, uint8_t *keep,
+                               float ratio)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (!db || !g_dbs.count(const_cast<ph_db *>(db)))
+        return fail(PH_ERR_INVALID_ARG, "not a live train-set handle");
+    if (k != 1 && k != 2)
+        return fail(PH_ERR_INVALID_ARG, "k must be 1 or 2 (got %d)", k);
+    if (keep && k != 2)
+        return fail(PH_ERR_INVALID_ARG, "the ratio test needs k == 2");
+    if ((s = check_rows(query, nq, "query")) != PH_OK)
+        return s;
+    if (nq > 0 && q_step < 32)
+        return fail(PH_ERR_INVALID_ARG, "row stride below 32 bytes");
+    if (nq == 0)
+        return PH_OK;
+    if (!out_idx || !out_dist)
+        return fail(PH_ERR_INVALID_ARG, "null output pointer");
+    hipStream_t st = g_ctx.stream;
+    const void *d_q = nullptr, *d_unused = nullptr;
+    if ((s = upload_descriptors(query, nq, q_step, nullptr, 0, 32, st, &d_q, &d_unused)) != PH_OK)
+        return s;
+    const size_t n_out = (size_t)nq * k;
+    const size_t dist_off = align256(n_out * 4), keep_off = dist_off + align256(n_out * 4);
+    PH_HIP(g_ctx.h_out.reserve(keep_off + (size_t)nq));
+    uint8_t *hb = (uint8_t *)g_ctx.h_out.p, *dbuf = (uint8_t *)g_ctx.h_out.dp;
+    if ((s = knn_dev_locked(d_q, nq, db->d, db->rows, k, 0, (int32_t *)dbuf,
+                            (int32_t *)(dbuf + dist_off), keep ? dbuf + keep_off : nullptr, ratio,
+                            g_ctx.part, st)) != PH_OK)
+        return s;
+    PH_HIP(hipStreamSynchronize(st));
+    memcpy(out_idx, hb, n_out * sizeof(int32_t));
+    memcpy(out_dist, hb + dist_off, n_out * sizeof(int32_t));
+    if (keep)
+        memcpy(keep, hb + keep_off, (size_t)nq);
+    return PH_OK;
 }
 
 ph_status ph_ransac_subsets(uint64_t rng_state, int n_points, int n_subsets, int32_t *out)

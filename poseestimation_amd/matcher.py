@@ -86,8 +86,91 @@ class BFMatcher:
         lib = _lib.load()
         if lib.ph_device() < 0:
             _lib.init(0)
+        self._train = []        # descriptor sets given to add(), one per train image
+        self._db = None         # handle of their resident concatenation
+        self._img_start = None  # first row of every train image in it
 
-    def match(self, queryDescriptors, trainDescriptors):
+    # ---- the train collection of cv2.DescriptorMatcher --------------------------------
+    def add(self, descriptors):
+        """DescriptorMatcher.add: one descriptor array per train image."""
+        if isinstance(descriptors, np.ndarray) and descriptors.ndim == 2:
+            descriptors = [descriptors]
+        for d in descriptors:
+            a, n, _ = _as_descriptors(d, "descriptors")
+            self._train.append(np.ascontiguousarray(a[:, :32]) if n else np.zeros((0, 32), np.uint8))
+        self._release_db()
+
+    def getTrainDescriptors(self):
+        return list(self._train)
+
+    def empty(self):
+        return not any(len(t) for t in self._train)
+
+    def clear(self):
+        self._train = []
+        self._release_db()
+
+    def train(self):
+        """Uploads the collection to the GPU once; match()/knnMatch() without a train
+        argument then send only the query descriptors."""
+        if self._db is not None:
+            return
+        allrows = (np.concatenate(self._train) if self._train else np.zeros((0, 32), np.uint8))
+        self._img_start = np.concatenate([[0], np.cumsum([len(t) for t in self._train])]).astype(np.int64)
+        h = C.c_void_p()
+        _lib.check(_lib.load().ph_db_upload(_u8(allrows), allrows.shape[0], 32, C.byref(h)))
+        self._db = h
+
+    def _release_db(self):
+        if getattr(self, "_db", None) is not None:
+            lib = _lib.load()
+            if lib.ph_db_rows(self._db) >= 0:     # not already released by ph_shutdown
+                lib.ph_db_free(self._db)
+        self._db = None
+
+    def __del__(self):
+        try:
+            self._release_db()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def _collection_knn(self, queryDescriptors, k):
+        """k-NN against the added collection: (idx, dist, imgIdx) arrays, idx local to the image."""
+        q, nq, qs = _as_descriptors(queryDescriptors, "queryDescriptors")
+        self.train()
+        lib = _lib.load()
+        if lib.ph_db_rows(self._db) < 0:          # the library was shut down in between
+            self._db = None
+            self.train()
+        idx = np.full((nq, k), _lib.NO_MATCH_IDX, np.int32)
+        dist = np.full((nq, k), _lib.NO_MATCH_DIST, np.int32)
+        i32 = C.POINTER(C.c_int32)
+        if nq and lib.ph_db_rows(self._db) > 0:
+            _lib.check(lib.ph_db_knn_hamming256(self._db, _u8(q), nq, qs, k, idx.ctypes.data_as(i32),
+                                                dist.ctypes.data_as(i32), None, 0.0))
+        img = np.searchsorted(self._img_start, np.maximum(idx, 0), side="right") - 1
+        local = idx - self._img_start[img].astype(np.int32)
+        local[idx < 0] = -1
+        return local, dist, img
+
+    def _collection_match(self, queryDescriptors, k):
+        if self.crossCheck:
+            # the cross-check needs the swapped search as well: one call on the concatenation
+            allrows = np.concatenate(self._train) if self._train else np.zeros((0, 32), np.uint8)
+            self.train()
+            flat = self.match(queryDescriptors, allrows)
+            for m in flat:
+                g = m.trainIdx
+                m.imgIdx = int(np.searchsorted(self._img_start, g, side="right") - 1)
+                m.trainIdx = int(g - self._img_start[m.imgIdx])
+            return [[m] for m in flat]
+        local, dist, img = self._collection_knn(queryDescriptors, k)
+        return [[DMatch(i, int(local[i, r]), int(img[i, r]), float(dist[i, r]))
+                 for r in range(k) if local[i, r] >= 0] for i in range(local.shape[0])]
+
+    def match(self, queryDescriptors, trainDescriptors=None):
+        if trainDescriptors is None:   # DescriptorMatcher.match(query): against the collection
+            return [row[0] for row in self._collection_match(queryDescriptors, 1) if row]
         q, nq, qs = _as_descriptors(queryDescriptors, "queryDescriptors")
         t, nt, ts = _as_descriptors(trainDescriptors, "trainDescriptors")
         lib = _lib.load()
@@ -97,7 +180,17 @@ class BFMatcher:
         _lib.check(fn(_u8(q), nq, qs, _u8(t), nt, ts, out, C.byref(n)))
         return _dm_list(out, n.value)
 
-    def knnMatch(self, queryDescriptors, trainDescriptors, k):
+    def knnMatch(self, queryDescriptors, trainDescriptors=None, k=None):
+        if k is None:                  # knnMatch(query, k): against the collection
+            if trainDescriptors is None or not isinstance(trainDescriptors, (int, np.integer)):
+                raise TypeError("knnMatch(query, k) or knnMatch(query, train, k)")
+            k, trainDescriptors = int(trainDescriptors), None
+        if trainDescriptors is None:
+            if self.crossCheck and k != 1:
+                raise ValueError("crossCheck requires k == 1")
+            if k < 1 or k > 2:
+                raise ValueError("k must be 1 or 2 (the hot path uses k = 1 and k = 2)")
+            return self._collection_match(queryDescriptors, k)
         if self.crossCheck and k != 1:
             # BFMatcher::knnMatchImpl asserts K == 1 when crossCheck is set
             raise ValueError("crossCheck requires k == 1")

@@ -572,3 +572,61 @@ def test_frames_uniform_batches(posehip, F, nq, nt):
         for qi, ti, _, d in orc.match(q[qo[f]:qo[f + 1]], t[to[f]:to[f + 1]], cross_check=True):
             want[qi] = ti
         assert np.array_equal(cidx[qo[f]:qo[f + 1]], want), f
+
+
+def test_resident_train_collection(posehip):
+    """DescriptorMatcher.add / train / match(query): three train images resident on the
+    GPU; results equal the oracle on the concatenation with (imgIdx, trainIdx) mapped back,
+    for match, knnMatch(k=2) and the cross-check; plus the raw handle API."""
+    import poseestimation_amd as pa
+    imgs = [datagen.codebook_descriptors(n, 120 + i, words=300) for i, n in enumerate([400, 1, 733])]
+    q = datagen.codebook_descriptors(500, 130, words=300)
+    cat = np.concatenate(imgs)
+    start = np.array([0, 400, 401])
+
+    def split(g):
+        i = int(np.searchsorted(start, g, side="right") - 1)
+        return i, int(g - start[i])
+
+    bf = pa.BFMatcher(pa.NORM_HAMMING)
+    assert bf.empty()
+    bf.add(imgs)
+    assert not bf.empty() and len(bf.getTrainDescriptors()) == 3
+    ridx, rdist = orc.knn(q, cat, 2)
+    for _ in range(2):      # second round: the set is already resident
+        got = bf.match(q)
+        assert [(m.queryIdx, m.imgIdx, m.trainIdx, m.distance) for m in got] == \
+            [(i, *split(ridx[i, 0]), float(rdist[i, 0])) for i in range(500)]
+    rows = bf.knnMatch(q, 2)
+    assert [[(m.imgIdx, m.trainIdx, m.distance) for m in r] for r in rows] == \
+        [[(*split(ridx[i, r]), float(rdist[i, r])) for r in range(2)] for i in range(500)]
+    cc = pa.BFMatcher(pa.NORM_HAMMING, crossCheck=True)
+    cc.add(imgs)
+    want = orc.match(q, cat, cross_check=True)
+    assert [(m.queryIdx, m.imgIdx, m.trainIdx, m.distance) for m in cc.match(q)] == \
+        [(a, *split(b), float(d)) for a, b, _, d in want]
+    bf.clear()
+    assert bf.empty() and bf.match(q) == []
+    # the handle API itself
+    lib = posehip.load()
+    h = C.c_void_p()
+    u8, i32 = C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    strided = np.zeros((cat.shape[0], 48), np.uint8)
+    strided[:, :32] = cat
+    posehip.check(lib.ph_db_upload(strided.ctypes.data_as(u8), cat.shape[0], 48, C.byref(h)))
+    assert lib.ph_db_rows(h) == cat.shape[0] and lib.ph_db_device_ptr(h)
+    idx, dist = np.zeros((500, 2), np.int32), np.zeros((500, 2), np.int32)
+    keep = np.zeros(500, np.uint8)
+    posehip.check(lib.ph_db_knn_hamming256(h, q.ctypes.data_as(u8), 500, 32, 2, idx.ctypes.data_as(i32),
+                                           dist.ctypes.data_as(i32), keep.ctypes.data_as(u8), 0.8))
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    kept = [m[0] for m in orc.ratio_filter(ridx, rdist, 0.8)]
+    assert np.nonzero(keep)[0].tolist() == kept
+    out = (posehip.DMatchC * 500)()
+    n = C.c_int(0)
+    posehip.check(lib.ph_ratio_filter(idx.ctypes.data_as(i32), dist.ctypes.data_as(i32), 500, 0.8, out,
+                                      C.byref(n)))
+    assert [(m.queryIdx, m.trainIdx, m.imgIdx, m.distance) for m in out[:n.value]] == \
+        orc.ratio_filter(ridx, rdist, 0.8)
+    posehip.check(lib.ph_db_free(h))
+    assert lib.ph_db_rows(h) == -1 and lib.ph_db_free(h) == 1    # dead handle: refused, no crash
