@@ -270,6 +270,183 @@ __device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep,
     }
 }
 
+// Forces a value to be computed where the statement stands.
+#define KEEP(x) asm volatile("" : "+v"(x))
+
+// ---- building blocks of the 12 x 12 decomposition ---------------------------------
+// Row i of a pass (i, i+1), (i, i+2), ... lives in registers with its squared norm.
+template <int N> struct JacobiRow {
+    double v[N], w;
+    bool dirty;
+    template <int ST> __device__ __forceinline__ void load(LP<ST> row, double norm2)
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            v[k] = row[k];
+        w = norm2;
+        dirty = false;
+    }
+    template <int ST> __device__ __forceinline__ void store(LP<ST> row, double &norm2) const
+    {
+        if (!dirty)
+            return;
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            row[k] = v[k];
+        norm2 = w;
+    }
+};
+
+// One pair (row in registers, row j in LDS) exactly as JacobiSVDImpl_ states it.
+template <int ST, int N>
+__device__ __forceinline__ void jacobi_pair(LP<ST> At, LP<ST> W, JacobiRow<N> &r, int j, double eps,
+                                            bool &changed)
+{
+    const LP<ST> Aj = At + j * N;
+    double aj[N];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        aj[k] = Aj[k];
+    double a = r.w, p = 0, b = W[j];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        p += r.v[k] * aj[k];
+    if (fabs(p) <= eps * sqrt(a * b))
+        return;
+    p *= 2;
+    const double beta = a - b, gamma = hypot_cr(p, beta);
+    double c, s;
+    jacobi_rotation(p, beta, gamma, c, s);
+    a = b = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const double t0 = c * r.v[k] + s * aj[k];
+        const double t1 = -s * r.v[k] + c * aj[k];
+        r.v[k] = t0;
+        Aj[k] = t1;
+        a += t0 * t0;
+        b += t1 * t1;
+    }
+    r.w = a;
+    W[j] = b;
+    changed = true;
+    r.dirty = true;
+}
+
+// The arithmetic of one pair without control flow, so that two of them can be issued
+// interleaved: every quantity is computed as in jacobi_pair and `rotate` says whether the
+// pair is past the convergence test; `plain` is false where hypot leaves its ordinary
+// range (non-finite, huge or tiny operands), which the caller hands to jacobi_pair.
+template <int N> struct PairMath {
+    double aj[N], nv[N], nj[N], na, nb, p, a, b;
+    bool rotate, plain;
+};
+
+// Partner row, dot product and convergence test.
+template <int ST, int N>
+__device__ __forceinline__ void jacobi_pair_test(LP<ST> At, LP<ST> W, const JacobiRow<N> &r, int j,
+                                                 double eps, PairMath<N> &m)
+{
+    const LP<ST> Aj = At + j * N;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        m.aj[k] = Aj[k];
+    m.a = r.w;
+    m.b = W[j];
+    double p = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        p += r.v[k] * m.aj[k];
+    m.p = p;
+    m.rotate = !(fabs(p) <= eps * sqrt(m.a * m.b));
+}
+
+// Rotation and rotated rows.
+template <int N>
+__device__ __forceinline__ void jacobi_pair_math(const JacobiRow<N> &r, PairMath<N> &m)
+{
+    const double p = m.p * 2;
+    const double beta = m.a - m.b;
+    // hypot_cr(p, beta) on its ordinary range
+    const double LARGE_VAL = 0x1p+511, TINY_VAL = 0x1p-459;
+    const double x = fabs(p), y = fabs(beta);
+    const double ax = x < y ? y : x, ay = x < y ? x : y;
+    const bool negligible = ax >= ay * 0x1p54; // == ay / 2^-54, exact
+    m.plain = (ax <= LARGE_VAL) & ((ay >= TINY_VAL) | negligible); // no short-circuit branches
+    double h = sqrt(ax * ax + ay * ay);
+    {
+        // both forms of hypot_kernel's correction, computed unconditionally (KEEP stops
+        // the compiler from sinking them into conditional regions, which would end the
+        // straight-line code the interleaving needs), then selected per lane
+        const bool near = h <= 2.0 * ay;
+        const double dn = h - ay, df = h - ax;
+        double t1n = ax * (2.0 * dn - ax), t2n = (dn - 2.0 * (ax - ay)) * dn;
+        double t1f = 2.0 * df * (ax - 2.0 * ay), t2f = (4.0 * df - ay) * ay + df * df;
+        KEEP(t1n); KEEP(t2n); KEEP(t1f); KEEP(t2f);
+        const double t1 = near ? t1n : t1f, t2 = near ? t2n : t2f;
+        h -= (t1 + t2) / (2.0 * h);
+    }
+    double sum = ax + ay;
+    KEEP(h); KEEP(sum);
+    const double gamma = negligible ? sum : h;
+    double c, s;
+    jacobi_rotation(p, beta, gamma, c, s);
+    double na = 0, nb = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const double t0 = c * r.v[k] + s * m.aj[k];
+        const double t1 = -s * r.v[k] + c * m.aj[k];
+        m.nv[k] = t0;
+        m.nj[k] = t1;
+        na += t0 * t0;
+        nb += t1 * t1;
+    }
+    m.na = na;
+    m.nb = nb;
+}
+
+template <int ST, int N>
+__device__ __forceinline__ void jacobi_pair_commit(LP<ST> At, LP<ST> W, JacobiRow<N> &r, int j,
+                                                   const PairMath<N> &m, bool &changed)
+{
+    if (!m.rotate)
+        return;
+    const LP<ST> Aj = At + j * N;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        r.v[k] = m.nv[k];
+        Aj[k] = m.nj[k];
+    }
+    r.w = m.na;
+    W[j] = m.nb;
+    changed = true;
+    r.dirty = true;
+}
+
+// Pairs (ra, ja) and (rb, jb) touch four different rows, so they commute; issuing their
+// dependent fp64 chains together nearly halves the time a lone wave spends waiting on
+// its own results.  Each pair's operations are those of jacobi_pair, bit for bit.
+template <int ST, int N>
+__device__ __forceinline__ void jacobi_pair2(LP<ST> At, LP<ST> W, JacobiRow<N> &ra, int ja,
+                                             JacobiRow<N> &rb, int jb, double eps, bool &changed)
+{
+    PairMath<N> ma, mb;
+    jacobi_pair_test<ST, N>(At, W, ra, ja, eps, ma);
+    jacobi_pair_test<ST, N>(At, W, rb, jb, eps, mb);
+    if (__builtin_amdgcn_ballot_w64(ma.rotate | mb.rotate) == 0)
+        return; // both pairs converged in every lane
+    jacobi_pair_math<N>(ra, ma);
+    jacobi_pair_math<N>(rb, mb);
+    const bool odd = (ma.rotate & !ma.plain) | (mb.rotate & !mb.plain);
+    if (__builtin_amdgcn_ballot_w64(odd) != 0) { // some lane needs hypot's special ranges
+        jacobi_pair<ST, N>(At, W, ra, ja, eps, changed);
+        jacobi_pair<ST, N>(At, W, rb, jb, eps, changed);
+        return;
+    }
+    jacobi_pair_commit<ST, N>(At, W, ra, ja, ma, changed);
+    jacobi_pair_commit<ST, N>(At, W, rb, jb, mb, changed);
+}
+
 // The 12 x 12 instance of jacobi_svd<ST, false> with row i held in registers
 // across the inner j loop (half the LDS traffic per rotation).  Same operations
 // in the same order, so the results are bit-identical to the generic routine.
@@ -288,51 +465,23 @@ template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
     }
     for (int iter = 0; iter < 30; iter++) {
         bool changed = false;
-        for (int i = 0; i < N - 1; i++) {
+        // Passes i and i + 1 run together, pass i + 1 one partner row behind pass i.
+        for (int i = 0; i < N - 1; i += 2) {
             const LP<ST> Ai = At + i * N;
-            double ai[N];
-#pragma unroll
-            for (int k = 0; k < N; k++)
-                ai[k] = Ai[k];
-            double wi = W[i];
-            bool dirty = false;
-            for (int j = i + 1; j < N; j++) {
-                const LP<ST> Aj = At + j * N;
-                double aj[N];
-#pragma unroll
-                for (int k = 0; k < N; k++)
-                    aj[k] = Aj[k];
-                double a = wi, p = 0, b = W[j];
-#pragma unroll
-                for (int k = 0; k < N; k++)
-                    p += ai[k] * aj[k];
-                if (fabs(p) <= eps * sqrt(a * b))
-                    continue;
-                p *= 2;
-                const double beta = a - b, gamma = hypot_cr(p, beta);
-                double c, s;
-                jacobi_rotation(p, beta, gamma, c, s);
-                a = b = 0;
-#pragma unroll
-                for (int k = 0; k < N; k++) {
-                    const double t0 = c * ai[k] + s * aj[k];
-                    const double t1 = -s * ai[k] + c * aj[k];
-                    ai[k] = t0;
-                    Aj[k] = t1;
-                    a += t0 * t0;
-                    b += t1 * t1;
-                }
-                wi = a;
-                W[j] = b;
-                changed = true;
-                dirty = true;
+            JacobiRow<N> ra, rb;
+            ra.load(Ai, W[i]);
+            jacobi_pair<ST, N>(At, W, ra, i + 1, eps, changed);
+            if (i + 1 >= N - 1) { // the last pass has no companion
+                ra.store(Ai, W[i]);
+                break;
             }
-            if (dirty) {
-#pragma unroll
-                for (int k = 0; k < N; k++)
-                    Ai[k] = ai[k];
-                W[i] = wi;
-            }
+            jacobi_pair<ST, N>(At, W, ra, i + 2, eps, changed);
+            rb.load(Ai + N, W[i + 1]);
+            for (int sj = i + 3; sj < N; sj++)
+                jacobi_pair2<ST, N>(At, W, ra, sj, rb, sj - 1, eps, changed);
+            jacobi_pair<ST, N>(At, W, rb, N - 1, eps, changed);
+            ra.store(Ai, W[i]);
+            rb.store(Ai + N, W[i + 1]);
         }
         if (!changed)
             break;
