@@ -447,9 +447,13 @@ __device__ __forceinline__ void jacobi_pair2(LP<ST> At, LP<ST> W, JacobiRow<N> &
     jacobi_pair_commit<ST, N>(At, W, rb, jb, mb, changed);
 }
 
-// The 12 x 12 instance of jacobi_svd<ST, false> with row i held in registers
-// across the inner j loop (half the LDS traffic per rotation).  Same operations
-// in the same order, so the results are bit-identical to the generic routine.
+// The 12 x 12 instance of jacobi_svd<ST, false>.  Row i of a pass is held in registers
+// across the inner j loop (half the LDS traffic per rotation), and passes i and i + 1 of
+// a sweep run together: at a step pass i works on (i, s) and pass i + 1 on (i + 1, s - 1),
+// which is after (i, i + 1) and (i, s - 1), the only earlier pairs that touch its two
+// rows.  Pairs on disjoint rows commute exactly (each rotation reads and writes its own
+// two rows and norms only), so every pair performs the operations it performs in the
+// cyclic order and the results are bit-identical to the generic routine.
 template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
 {
     constexpr int N = 12;
