@@ -1,5 +1,5 @@
 // Per-phase cycle counts of one RANSAC-EPnP hypothesis (wave 0), for tuning.
-// build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -DPNP_STAMPS -Iposeestimation_amd/csrc tools/pnp_stamps.hip -o tools/pnp_stamps
+// build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-sched-strategy=max-ilp -DPNP_STAMPS -Iposeestimation_amd/csrc tools/pnp_stamps.hip -o tools/pnp_stamps
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
