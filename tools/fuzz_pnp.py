@@ -1,0 +1,41 @@
+"""Randomised differential run of solvePnPRansac (batched and single) against the CPU oracle:
+random correspondence counts, outlier fractions, noise, iteration budgets, thresholds.
+Not part of the test suite:  python tools/fuzz_pnp.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import datagen, oracle_bind as orc
+import poseestimation_amd as pa
+pa._lib.init(0)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end, n_prob, worst = time.time() + budget, 0, 0.0
+while time.time() < t_end:
+    P = int(rng.integers(1, 24))
+    iters = int(rng.choice([1, 7, 50, 100, 333]))
+    thr = float(rng.choice([1.0, 3.0, 8.0]))
+    scenes = []
+    for _ in range(P):
+        n = int(rng.choice([5, 6, 7, 20, 64, 65, 200, 500, 900]))
+        scenes.append(datagen.pnp_scene(n=n, outlier_frac=float(rng.choice([0.0, 0.2, 0.5, 0.9])),
+                                        noise_px=float(rng.choice([0.0, 0.5, 2.0])), seed=int(rng.integers(1 << 30)),
+                                        angle_deg=float(rng.uniform(-80, 80)), on_faces=bool(rng.random() < 0.3)))
+    objs, imgs = [s[0] for s in scenes], [s[1] for s in scenes]
+    res = pa.solvePnPRansacBatch(objs, imgs, datagen.CAMERA_K, None, iterationsCount=iters,
+                                 reprojectionError=thr, returnIterations=True)
+    for obj, img, (ok, rvec, tvec, inl, it) in zip(objs, imgs, res):
+        ok0, r0, t0, inl0, it0 = orc.solvepnp_ransac(obj, img, datagen.CAMERA_K, iterations=iters, reproj_err=thr)
+        assert ok == ok0, (len(obj), iters, thr, ok, ok0)
+        if len(obj) > 5:
+            assert it == it0, (len(obj), iters, it, it0)
+        if ok:
+            assert np.array_equal(inl.ravel(), inl0), (len(obj), iters, thr)
+            Ra, Rb = orc.rodrigues(rvec.ravel()), orc.rodrigues(np.ravel(r0))
+            e = max(np.linalg.norm(Ra - Rb) / np.linalg.norm(Ra),
+                    np.linalg.norm(tvec.ravel() - np.ravel(t0)) / np.linalg.norm(tvec))
+            if np.isfinite(e):
+                worst = max(worst, e)
+                assert e <= 1e-4, (len(obj), iters, thr, e)
+        n_prob += 1
+print({"problems": n_prob, "worst_relative_pose_difference": worst, "ok": True})
