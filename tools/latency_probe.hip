@@ -43,6 +43,16 @@ int main()
     for (int i = 0; i < 10; i++) ph_match_crosscheck_hamming256((const uint8_t *)q.data(), 500, 32, (const uint8_t *)t.data(), 500, 32, out.data(), &n);
     printf(" \"crosscheck_500x500_host_call_us\": %.1f,\n", med([&] { ph_match_crosscheck_hamming256((const uint8_t *)q.data(), 500, 32, (const uint8_t *)t.data(), 500, 32, out.data(), &n); }));
     printf(" \"match_500x500_host_call_us\": %.1f}\n", med([&] { ph_match_hamming256((const uint8_t *)q.data(), 500, 32, (const uint8_t *)t.data(), 500, 32, out.data(), &n); }));
+    {   // the benchmark's frame through the host entry point: PCIe both ways included
+        const int n = 10000;
+        std::vector<uint64_t> bq((size_t)n * 4), bt((size_t)n * 4);
+        for (auto &v : bq) v = rng();
+        for (auto &v : bt) v = rng();
+        std::vector<ph_dmatch> bo(n); int bn = 0;
+        for (int i = 0; i < 5; i++) ph_knn2_ratio_hamming256((const uint8_t *)bq.data(), n, 32, (const uint8_t *)bt.data(), n, 32, 0.75f, bo.data(), &bn);
+        const double us = med([&] { ph_knn2_ratio_hamming256((const uint8_t *)bq.data(), n, 32, (const uint8_t *)bt.data(), n, 32, 0.75f, bo.data(), &bn); }, 100);
+        printf("{\"knn2_ratio_10k_x_10k_host_call_us\": %.1f, \"evals_per_s_pcie_inclusive\": %.4g}\n", us, 1e8 / (us * 1e-6));
+    }
     ph_shutdown();
     return 0;
 }
