@@ -31,7 +31,11 @@ def descs(n, ties):
 
 
 t_end, n_cases = time.time() + budget, 0
+last = time.time()
 while time.time() < t_end:
+    if time.time() - last > 20:
+        print({'progress': n_cases}, flush=True)
+        last = time.time()
     ties = rng.random() < 0.5
     mode = rng.choice(["host", "frames", "uniform"])
     k = int(rng.choice([1, 2]))

@@ -11,7 +11,11 @@ pa._lib.init(0)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end, n_prob, worst = time.time() + budget, 0, 0.0
+last = time.time()
 while time.time() < t_end:
+    if time.time() - last > 20:
+        print({'progress': n_prob}, flush=True)
+        last = time.time()
     P = int(rng.integers(1, 24))
     iters = int(rng.choice([1, 7, 50, 100, 333]))
     thr = float(rng.choice([1.0, 3.0, 8.0]))
