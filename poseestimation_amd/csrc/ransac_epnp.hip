@@ -148,12 +148,21 @@ template <int ST> struct LP {
 // vectors, W descending.  Same sweep order, thresholds and zero-row completion
 // as OpenCV's JacobiSVDImpl_<double>.  W is an n-entry work array.  WITH_V =
 // false skips the right-vector accumulation (it never feeds back into At or W).
-template <int ST, bool WITH_V>
+// M, N > 0 fix the sizes at compile time (astep == M, vstep == N): the rows of a pair are
+// then read into registers in one batch and the loops over their elements unroll, instead
+// of one LDS round trip per element.  Same operations in the same order either way.
+template <int ST, bool WITH_V, int M = 0, int N = 0>
 __device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep, int m, int n)
 {
     const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
     const int max_iter = m > 30 ? m : 30;
     double c, s;
+    if constexpr (M > 0) {
+        m = M;
+        n = N;
+        astep = M;
+        vstep = N;
+    }
     for (int i = 0; i < n; i++) {
         double sd = 0;
         for (int k = 0; k < m; k++) {
@@ -173,6 +182,50 @@ __device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep,
             for (int j = i + 1; j < n; j++) {
                 const LP<ST> Ai = At + i * astep, Aj = At + j * astep;
                 double a = W[i], p = 0, b = W[j];
+                if constexpr (M > 0) {
+                    double ai[M], aj[M];
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        ai[k] = Ai[k];
+                        aj[k] = Aj[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < M; k++)
+                        p += ai[k] * aj[k];
+                    if (fabs(p) <= eps * sqrt(a * b))
+                        continue;
+                    p *= 2;
+                    const double beta = a - b, gamma = hypot_cr(p, beta);
+                    jacobi_rotation(p, beta, gamma, c, s);
+                    a = b = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        const double t0 = c * ai[k] + s * aj[k];
+                        const double t1 = -s * ai[k] + c * aj[k];
+                        Ai[k] = t0;
+                        Aj[k] = t1;
+                        a += t0 * t0;
+                        b += t1 * t1;
+                    }
+                    W[i] = a;
+                    W[j] = b;
+                    changed = true;
+                    if (WITH_V) {
+                        const LP<ST> Vi = Vt + i * N, Vj = Vt + j * N;
+                        double vi[N], vj[N];
+#pragma unroll
+                        for (int k = 0; k < N; k++) {
+                            vi[k] = Vi[k];
+                            vj[k] = Vj[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < N; k++) {
+                            Vi[k] = c * vi[k] + s * vj[k];
+                            Vj[k] = -s * vi[k] + c * vj[k];
+                        }
+                    }
+                    continue;
+                }
                 for (int k = 0; k < m; k++)
                     p += Ai[k] * Aj[k];
                 if (fabs(p) <= eps * sqrt(a * b))
@@ -583,14 +636,24 @@ template <int ST> struct EpnpLds {
 // the call S.sa holds Ut (rows = left singular vectors), S.sv holds Vt.
 template <int ST> __device__ void svd_small_square(const EpnpLds<ST> &S, int n)
 {
-    jacobi_svd<ST, true>(S.sa, n, S.sw, S.sv, n, n, n);
+    if (n == 3)
+        jacobi_svd<ST, true, 3, 3>(S.sa, 3, S.sw, S.sv, 3, 3, 3);
+    else
+        jacobi_svd<ST, true>(S.sa, n, S.sw, S.sv, n, n, n);
 }
 
 // cv::solve(A, b, x, DECOMP_SVD) with A (m x n) already TRANSPOSED in S.sa (n x m).
 template <int ST>
 __device__ void solve_svd(const EpnpLds<ST> &S, int m, int n, const double *b, double *x)
 {
-    jacobi_svd<ST, true>(S.sa, m, S.sw, S.sv, n, m, n);
+    if (m == 6 && n == 4)
+        jacobi_svd<ST, true, 6, 4>(S.sa, 6, S.sw, S.sv, 4, 6, 4);
+    else if (m == 6 && n == 3)
+        jacobi_svd<ST, true, 6, 3>(S.sa, 6, S.sw, S.sv, 3, 6, 3);
+    else if (m == 6 && n == 5)
+        jacobi_svd<ST, true, 6, 5>(S.sa, 6, S.sw, S.sv, 5, 6, 5);
+    else
+        jacobi_svd<ST, true>(S.sa, m, S.sw, S.sv, n, m, n);
     double threshold = 0;
     for (int i = 0; i < n; i++) {
         x[i] = 0;
