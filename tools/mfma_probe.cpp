@@ -1,0 +1,207 @@
+// Matrix-core k-NN probe: exactness against a CPU brute force on tie-heavy data, then
+// timing.  Build (from the repo root):
+//   hipcc --offload-arch=gfx950 -O3 -x hip tools/mfma_probe.cpp \
+//         poseestimation_amd/csrc/knn_mfma.hip -o tools/mfma_probe
+// Run: tools/mfma_probe [nq nt splits q_tiles reps]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../poseestimation_amd/csrc/knn_hamming.h"
+#include "../poseestimation_amd/csrc/knn_mfma.h"
+
+using namespace posehip;
+
+#define CK(x)                                                                                     \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) {                                                                   \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));     \
+            exit(2);                                                                              \
+        }                                                                                         \
+    } while (0)
+
+static int ham(const uint32_t *a, const uint32_t *b)
+{
+    int d = 0;
+    for (int i = 0; i < 8; i++)
+        d += __builtin_popcount(a[i] ^ b[i]);
+    return d;
+}
+
+// rows drawn from a small pool with a few flipped bits: many equal distances
+static std::vector<uint32_t> make_rows(int64_t n, int pool, int flips, uint32_t seed)
+{
+    std::mt19937 g(seed);
+    std::vector<uint32_t> base((size_t)pool * 8), out((size_t)n * 8);
+    for (auto &w : base)
+        w = g();
+    for (int64_t i = 0; i < n; i++) {
+        const int p = (int)(g() % (uint32_t)pool);
+        for (int j = 0; j < 8; j++)
+            out[i * 8 + j] = base[(size_t)p * 8 + j];
+        for (int f = 0; f < flips; f++) {
+            const uint32_t bit = g() & 255;
+            out[i * 8 + (bit >> 5)] ^= 1u << (bit & 31);
+        }
+    }
+    return out;
+}
+
+static int check(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int k, int pool, int flips)
+{
+    auto q = make_rows(nq, pool, flips, 1 + (uint32_t)nq), t = make_rows(nt, pool, flips, 7 + (uint32_t)nt);
+    if (pool == 1 && nt > 3) { // complement rows: distance 256
+        for (int j = 0; j < 8; j++)
+            t[8 * 3 + j] = ~q[j];
+    }
+    void *dq, *dt, *dqx, *dtx;
+    uint32_t *dpart;
+    CK(hipMalloc(&dq, nq * 32));
+    CK(hipMalloc(&dt, nt * 32));
+    CK(hipMalloc(&dqx, knn_mfma_expanded_bytes(nq)));
+    CK(hipMalloc(&dtx, knn_mfma_expanded_bytes(nt)));
+    CK(hipMemset(dqx, 0xFF, knn_mfma_expanded_bytes(nq)));
+    CK(hipMemset(dtx, 0xFF, knn_mfma_expanded_bytes(nt)));
+    CK(hipMemcpy(dq, q.data(), nq * 32, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dt, t.data(), nt * 32, hipMemcpyHostToDevice));
+    MfmaPlan p = knn_mfma_plan_splits(nq, nt, q_tiles, splits);
+    CK(hipMalloc(&dpart, p.part_bytes));
+    CK(knn_mfma_expand_launch(dq, nq, dqx, 0));
+    CK(knn_mfma_expand_launch(dt, nt, dtx, 0));
+    CK(knn_mfma_partial_launch(p, dqx, nq, dtx, nt, k, dpart, 0));
+    CK(hipDeviceSynchronize());
+    std::vector<uint32_t> part(p.part_bytes / 4);
+    CK(hipMemcpy(part.data(), dpart, p.part_bytes, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int64_t i = 0; i < nq; i++) {
+        // expected: two smallest (dist, idx)
+        uint64_t e1 = ~0ull, e2 = ~0ull;
+        for (int64_t j = 0; j < nt; j++) {
+            const uint64_t key = ((uint64_t)ham(&q[i * 8], &t[j * 8]) << 32) | (uint64_t)j;
+            if (key < e1) {
+                e2 = e1;
+                e1 = key;
+            } else if (key < e2)
+                e2 = key;
+        }
+        uint64_t g1 = ~0ull, g2 = ~0ull;
+        for (int s = 0; s < p.n_splits; s++)
+            for (int rnk = 0; rnk < 2; rnk++) {
+                const uint32_t kk = part[((size_t)s * 2 + rnk) * nq + i];
+                if (kk == 0xFFFFFFFFu)
+                    continue;
+                const uint64_t key = ((uint64_t)(kk >> KNN_KEY_SHIFT) << 32) |
+                                     (uint64_t)(s * p.rows_per_split + (kk & ((1u << KNN_KEY_SHIFT) - 1)));
+                if (key < g1) {
+                    g2 = g1;
+                    g1 = key;
+                } else if (key < g2)
+                    g2 = key;
+            }
+        if (k == 1) {
+            e2 = ~0ull;
+            g2 = ~0ull;
+        }
+        if (g1 != e1 || g2 != e2) {
+            if (bad < 5)
+                printf("  MISMATCH q=%lld: got (%llu,%llu) (%llu,%llu) want (%llu,%llu) (%llu,%llu)\n",
+                       (long long)i, (unsigned long long)(g1 >> 32), (unsigned long long)(g1 & 0xFFFFFFFF),
+                       (unsigned long long)(g2 >> 32), (unsigned long long)(g2 & 0xFFFFFFFF),
+                       (unsigned long long)(e1 >> 32), (unsigned long long)(e1 & 0xFFFFFFFF),
+                       (unsigned long long)(e2 >> 32), (unsigned long long)(e2 & 0xFFFFFFFF));
+            bad++;
+        }
+    }
+    printf("check nq=%lld nt=%lld splits=%d rows/split=%lld q_tiles=%d k=%d pool=%d flips=%d: %s (%d bad)\n",
+           (long long)nq, (long long)nt, p.n_splits, (long long)p.rows_per_split, q_tiles, k, pool,
+           flips, bad ? "FAIL" : "ok", bad);
+    fflush(stdout);
+    CK(hipFree(dq));
+    CK(hipFree(dt));
+    CK(hipFree(dqx));
+    CK(hipFree(dtx));
+    CK(hipFree(dpart));
+    return bad;
+}
+
+static void timeit(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int reps)
+{
+    auto q = make_rows(nq, 1 << 20, 0, 3), t = make_rows(nt, 1 << 20, 0, 5);
+    void *dq, *dt, *dqx, *dtx;
+    uint32_t *dpart;
+    CK(hipMalloc(&dq, nq * 32));
+    CK(hipMalloc(&dt, nt * 32));
+    CK(hipMalloc(&dqx, knn_mfma_expanded_bytes(nq)));
+    CK(hipMalloc(&dtx, knn_mfma_expanded_bytes(nt)));
+    CK(hipMemcpy(dq, q.data(), nq * 32, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dt, t.data(), nt * 32, hipMemcpyHostToDevice));
+    MfmaPlan p = knn_mfma_plan_splits(nq, nt, q_tiles, splits);
+    CK(hipMalloc(&dpart, p.part_bytes));
+    hipEvent_t e0, e1, e2;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventCreate(&e2));
+    float best_x = 1e30f, best_k = 1e30f;
+    for (int r = 0; r < reps + 2; r++) {
+        CK(hipEventRecord(e0, 0));
+        CK(knn_mfma_expand_launch(dq, nq, dqx, 0));
+        CK(knn_mfma_expand_launch(dt, nt, dtx, 0));
+        CK(hipEventRecord(e1, 0));
+        CK(knn_mfma_partial_launch(p, dqx, nq, dtx, nt, 2, dpart, 0));
+        CK(hipEventRecord(e2, 0));
+        CK(hipEventSynchronize(e2));
+        float mx, mk;
+        CK(hipEventElapsedTime(&mx, e0, e1));
+        CK(hipEventElapsedTime(&mk, e1, e2));
+        if (r >= 2) {
+            best_x = std::min(best_x, mx);
+            best_k = std::min(best_k, mk);
+        }
+    }
+    const double evals = (double)nq * (double)nt;
+    printf("time nq=%lld nt=%lld splits=%d rows/split=%lld q_tiles=%d grid=%lldx%d: expand %.1f us, "
+           "kernel %.1f us = %.3e evals/s = %.2f PFLOP/s fp4\n",
+           (long long)nq, (long long)nt, p.n_splits, (long long)p.rows_per_split, q_tiles,
+           (long long)p.q_blocks, p.n_splits, best_x * 1e3, best_k * 1e3, evals / (best_k * 1e-3),
+           evals * 512 / (best_k * 1e-3) / 1e15);
+    fflush(stdout);
+    CK(hipFree(dq));
+    CK(hipFree(dt));
+    CK(hipFree(dqx));
+    CK(hipFree(dtx));
+    CK(hipFree(dpart));
+}
+
+int main(int argc, char **argv)
+{
+    if (argc >= 5) {
+        timeit(atoll(argv[1]), atoll(argv[2]), atoll(argv[3]), atoi(argv[4]),
+               argc > 5 ? atoi(argv[5]) : 5);
+        return 0;
+    }
+    int bad = 0;
+    for (int qt : {4, 2, 8})
+        for (int k : {2, 1}) {
+            bad += check(700, 3001, 3, qt, k, 16, 3);
+            bad += check(33, 40, 1, qt, k, 4, 1);
+            bad += check(1, 1, 1, qt, k, 1, 0);
+            bad += check(513, 31, 1, qt, k, 1, 0);
+            bad += check(300, 2000, 1, qt, k, 1, 0); // all distances equal except row 3
+            bad += check(1500, 5000, 7, qt, k, 1 << 20, 0);
+        }
+    bad += check(64, 40000, 1, 4, 2, 8, 2); // two splits of 32768 / 7232 rows: 1024 tiles
+    printf(bad ? "PROBE FAILED\n" : "PROBE OK\n");
+    if (bad)
+        return 1;
+    for (int qt : {4, 8, 2})
+        for (int splits : {1, 2, 4, 8})
+            timeit(163840, 10000, splits, qt, 5);
+    return 0;
+}
