@@ -271,6 +271,15 @@ ph_status ph_knn_last_timing(float *distance_kernel_ms, float *merge_kernel_ms);
  * the fixed cost the two figures above include on top of the kernels' own time. */
 ph_status ph_knn_last_timing_overhead(float *empty_interval_ms);
 
+/* The distance kernel exists twice: a popcount kernel on the vector ALUs and a
+ * matrix-core kernel (descriptor bits as FP4 +-4, Hamming distance from the dot
+ * product), bit-identical in their results.  mode 0 (default) picks by problem
+ * size, 1 always takes the popcount kernel, 2 always the matrix cores.  May be
+ * called before ph_init; ph_shutdown resets it to 0.  ph_knn_last_path: which
+ * one the last k-NN call of this process ran (0 popcount, 1 matrix cores). */
+ph_status ph_knn_set_path(int mode);
+int ph_knn_last_path(void);
+
 /* Sustained VALU rate, in lane-operations per second, of the instruction pair
  * the distance loop is made of (v_xor_b32 with a scalar operand + accumulating
  * v_bcnt_u32_b32), 8 waves per SIMD on every CU, `iters` x 128 operations per

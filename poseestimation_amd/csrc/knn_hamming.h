@@ -47,6 +47,21 @@ hipError_t knn_frames_launch(const KnnPlan &p, const void *d_query, const int32_
                              hipStream_t stream, hipEvent_t *events = nullptr,
                              bool uniform_frames = false);
 
+// Folds the per-split keys part[split][rank][nq] (distance << KNN_KEY_SHIFT | row in
+// split) into the k-NN rows.
+hipError_t knn_merge_launch(const uint32_t *d_part, int64_t nq, int n_splits,
+                            int64_t rows_per_split, int k, int32_t index_base,
+                            int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep, float ratio,
+                            hipStream_t stream);
+
+// The same for a batch of frames of at most max_nq query rows each.  waves > 0: the
+// splits of knn_frames_launch with that many waves; waves < 0: the matrix-core kernel's.
+hipError_t knn_merge_frames_launch(const uint32_t *d_part, const int32_t *d_q_off,
+                                   const int32_t *d_t_off, int64_t total_nq, int64_t max_nq,
+                                   int n_frames, int n_splits, int waves, int k,
+                                   int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,
+                                   float ratio, hipStream_t stream);
+
 // Train rows per split of a frame with nt train rows under plan p.
 int64_t frame_rows_per_split(int64_t nt, const KnnPlan &p);
 

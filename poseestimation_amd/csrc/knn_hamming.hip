@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "knn_hamming.h"
+#include "knn_mfma.h"
 
 namespace posehip {
 
@@ -384,6 +385,8 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint32_t *__restri
 }
 
 // Merge for a batch of frames (grid.y = frame); train indices are local to the frame.
+// waves > 0: splits as knn_partial_frames_kernel cuts them; waves < 0: as the matrix-core
+// kernel does (multiples of its 32-row tile).
 __global__ __launch_bounds__(256) void knn_merge_frames_kernel(
     const uint32_t *__restrict__ part, const int32_t *__restrict__ q_off,
     const int32_t *__restrict__ t_off, int64_t total_nq, int n_splits, int waves, int k,
@@ -395,8 +398,10 @@ __global__ __launch_bounds__(256) void knn_merge_frames_kernel(
     const int64_t row0 = q0 + (int64_t)blockIdx.x * 64;
     if (row0 >= q1)
         return;
-    const FrameGeom g = frame_geom((int64_t)t_off[f + 1] - t_off[f], n_splits, waves);
-    knn_merge_body(part, total_nq, row0, q1, n_splits, g.rows_per_split, k, 0, out_idx, out_dist,
+    const int64_t nt = (int64_t)t_off[f + 1] - t_off[f];
+    const int64_t rows_per_split = waves > 0 ? frame_geom(nt, n_splits, waves).rows_per_split
+                                             : mfma_rows_per_split(nt, n_splits);
+    knn_merge_body(part, total_nq, row0, q1, n_splits, rows_per_split, k, 0, out_idx, out_dist,
                    keep, ratio);
 }
 
@@ -607,6 +612,28 @@ hipError_t knn_launch(const KnnPlan &p, const void *d_query, int64_t nq, const v
     if (events && (e = hipEventRecord(events[3], stream)) != hipSuccess)
         return e;
     return hipSuccess;
+}
+
+hipError_t knn_merge_launch(const uint32_t *d_part, int64_t nq, int n_splits,
+                            int64_t rows_per_split, int k, int32_t index_base,
+                            int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep, float ratio,
+                            hipStream_t stream)
+{
+    knn_merge_kernel<<<(unsigned)((nq + 63) / 64), 256, 0, stream>>>(
+        d_part, nq, n_splits, rows_per_split, k, index_base, d_out_idx, d_out_dist, d_keep, ratio);
+    return hipGetLastError();
+}
+
+hipError_t knn_merge_frames_launch(const uint32_t *d_part, const int32_t *d_q_off,
+                                   const int32_t *d_t_off, int64_t total_nq, int64_t max_nq,
+                                   int n_frames, int n_splits, int waves, int k,
+                                   int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,
+                                   float ratio, hipStream_t stream)
+{
+    knn_merge_frames_kernel<<<dim3((unsigned)((max_nq + 63) / 64), (unsigned)n_frames), 256, 0,
+                              stream>>>(d_part, d_q_off, d_t_off, total_nq, n_splits, waves, k,
+                                        d_out_idx, d_out_dist, d_keep, ratio);
+    return hipGetLastError();
 }
 
 KnnPlan knn_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int64_t total_nq, int n_cus)

@@ -8,17 +8,31 @@ namespace posehip {
 
 static constexpr int MF_WAVES = 4;                      // waves per workgroup
 static constexpr int64_t MF_MAX_ROWS_PER_SPLIT = 32768; // 1024 tiles: the key's index field
-// Rows an expanded buffer is readable past its last row: a workgroup's query block
-// (up to 4 waves x 8 tiles x 32 rows) and a train tile may run over the end.
+// Rows an FP4 image is readable past its last row: a workgroup's query block (4 waves x
+// 4 tiles x 32 rows) and the train tiles loaded ahead may run over the end.
 static constexpr int64_t MF_PAD_ROWS = 1024;
 
 struct MfmaPlan {
-    int q_tiles;            // tiles of 32 queries per wave (2, 4 or 8)
+    int q_tiles;            // tiles of 32 queries per wave (2 or 4)
     int64_t q_blocks;       // grid.x: blocks of 128 * q_tiles queries
     int n_splits;           // grid.y: train-row splits
-    int64_t rows_per_split; // multiple of 32
+    int64_t rows_per_split; // multiple of 32 (of the largest frame, for a batch)
     size_t part_bytes;
 };
+
+// Train rows per split of a problem with nt train rows cut into n_splits (multiples of
+// the 32-row tile).
+__host__ __device__ inline int64_t mfma_rows_per_split(int64_t nt, int n_splits)
+{
+    int64_t rows = (nt + n_splits - 1) / n_splits;
+    rows = (rows + 31) & ~(int64_t)31;
+    return rows < 32 ? 32 : rows;
+}
+
+// Whether the matrix-core path is the faster one for a problem / a batch of this size
+// (below, the two extra launches and the FP4 images cost more than they save).
+bool knn_mfma_pays(int64_t nq, int64_t nt);
+bool knn_mfma_pays_frames(int n_frames, int64_t max_nq, int64_t max_nt);
 
 // Bytes of the FP4 image of `rows` descriptors (128 per row, padding included).
 size_t knn_mfma_expanded_bytes(int64_t rows);
@@ -27,12 +41,28 @@ size_t knn_mfma_expanded_bytes(int64_t rows);
 hipError_t knn_mfma_expand_launch(const void *d_rows, int64_t rows, void *d_expanded,
                                   hipStream_t stream);
 
+MfmaPlan knn_mfma_plan(int64_t nq, int64_t nt, int n_cus);
 MfmaPlan knn_mfma_plan_splits(int64_t nq, int64_t nt, int q_tiles, int64_t splits);
+MfmaPlan knn_mfma_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int64_t total_nq,
+                              int n_cus);
 
-// Writes part[split][rank][nq] keys (distance << KNN_KEY_SHIFT | row in split), the
-// format knn_merge_kernel folds.
-hipError_t knn_mfma_partial_launch(const MfmaPlan &p, const void *d_qx, int64_t nq,
-                                   const void *d_tx, int64_t nt, int k, uint32_t *d_part,
-                                   hipStream_t stream);
+// Same contract as knn_launch: FP4 images of both sets (d_qx / d_tx, workspaces of
+// knn_mfma_expanded_bytes), the distance kernel, the merge of the splits.  events, when
+// given, bracket the distance kernel [0, 1] and the merge [1, 2]; [2, 3] is empty.
+hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, const void *d_train,
+                           int64_t nt, int k, int32_t index_base, void *d_qx, void *d_tx,
+                           uint32_t *d_part, int32_t *d_out_idx, int32_t *d_out_dist,
+                           uint8_t *d_keep, float ratio, hipStream_t stream,
+                           hipEvent_t *events = nullptr);
+
+// Same contract as knn_frames_launch; [q_begin, q_end) / [t_begin, t_end) are the row
+// ranges the offset tables span (q_end rows of part / outputs are addressed).
+hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const int32_t *d_q_off,
+                                  int64_t q_begin, int64_t q_end, const void *d_train,
+                                  const int32_t *d_t_off, int64_t t_begin, int64_t t_end,
+                                  int n_frames, int k, void *d_qx, void *d_tx, uint32_t *d_part,
+                                  int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,
+                                  float ratio, hipStream_t stream, hipEvent_t *events = nullptr,
+                                  bool uniform_frames = false);
 
 } // namespace posehip

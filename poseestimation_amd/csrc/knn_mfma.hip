@@ -20,8 +20,8 @@
 // 16 keys where the popcount kernel spends 292.
 //
 // A workgroup is 4 waves; wave w holds QT tiles of 32 queries as B fragments in registers
-// for the whole kernel, all four waves stream the same train tiles, staged through LDS in
-// fragment order (one 16-byte piece per thread and tile, loaded a tile ahead).
+// for the whole kernel, all four waves stream the same train tiles, which an LDS-DMA ring
+// (global_load_lds, no VGPRs) stages in fragment order three tiles ahead.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -120,32 +120,70 @@ __device__ __forceinline__ void fold_tile(f32x16 acc, float &m1, float &m2, int 
         top2_max4<K>(m1, m2, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
 }
 
-// One train tile against the wave's QT query tiles.  MASKED: rows at or beyond `valid`
-// (the tail of the last tile) are taken out before the fold.  The MFMAs of query tile
-// j + 1 are issued ahead of the fold of tile j (two accumulator sets), and the scheduler
-// is told to keep that interleaving: one MFMA, then a share of the fold's VALU work.
-template <int K, int QT, bool MASKED>
-__device__ __forceinline__ void mfma_tile(const i32x8 (&a)[4], const i32x8 (&b)[QT][4],
+// One train tile against the wave's QT query tiles, software-pipelined with a lag of
+// two: while the four MFMAs of query tile j run, the VALU folds the keys of query tile
+// j - 2, so that no fold starts within the latency of the MFMA that produced its keys.
+// The keys of the tile's last two query tiles stay in pend0 / pend1 (older first) and are
+// folded under the first MFMAs of the NEXT train tile; on entry they hold the previous
+// train tile's.  LAST: this is the split's last tile, whose rows at or beyond `valid`
+// are taken out before the fold (the pending keys of the tile before are complete).
+// RELOAD: once every MFMA is issued, fetch the next tile's fragments.  The scheduler is
+// told to keep one MFMA per five or six VALU instructions, which is what the MFMA pipe
+// (32 cycles each) can hide.
+template <int K, int QT, bool LAST, bool RELOAD>
+__device__ __forceinline__ void mfma_tile(i32x8 (&a)[4], const i32x8 (&b)[QT][4],
                                           const f32x16 &c0, float (&m1)[QT], float (&m2)[QT],
-                                          int valid, int h)
+                                          f32x16 &pend0, f32x16 &pend1, int valid, int h,
+                                          const uint4 *next_frags)
 {
-    f32x16 cur = mfma_chain(a, b[0], c0);
+    static_assert(QT >= 2, "the fold lags two query tiles behind");
 #pragma unroll
     for (int j = 0; j < QT; j++) {
-        f32x16 nxt;
-        if (j + 1 < QT)
-            nxt = mfma_chain(a, b[j + 1], c0);
-        fold_tile<K, MASKED>(cur, m1[j], m2[j], valid, h);
-        if (!MASKED && j + 1 < QT) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 6 : 3, 0); // VALU
-            }
-        }
-        if (j + 1 < QT)
-            cur = nxt;
+        const f32x16 acc = mfma_chain(a, b[j], c0);
+        const int jf = (j + QT - 2) % QT; // the query tile pend0 belongs to
+        if (LAST && j >= 2)
+            fold_tile<K, true>(pend0, m1[jf], m2[jf], valid, h);
+        else
+            fold_tile<K, false>(pend0, m1[jf], m2[jf], valid, h);
+        pend0 = pend1;
+        pend1 = acc;
     }
+    if constexpr (RELOAD) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            a[s] = frag(next_frags[s * 64]);
+    }
+    if constexpr (!LAST) {
+#pragma unroll
+        for (int j = 0; j < QT; j++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 6 : 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 6 : 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 5 : 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 5 : 2, 0);
+        }
+    }
+}
+
+// The folds still pending after a split's last tile (both belong to that tile).
+template <int K, int QT>
+__device__ __forceinline__ void fold_pending(float (&m1)[QT], float (&m2)[QT], const f32x16 &pend0,
+                                             const f32x16 &pend1, int valid, int h)
+{
+    fold_tile<K, true>(pend0, m1[QT - 2], m2[QT - 2], valid, h);
+    fold_tile<K, true>(pend1, m1[QT - 1], m2[QT - 1], valid, h);
+}
+
+// 16 bytes per lane from global memory straight into LDS (no VGPR in between): the wave's
+// 64 pieces land at lds_wave_base + 16 * lane.
+__device__ __forceinline__ void load_to_lds(const uint4 *g, uint4 *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)g,
+        (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
 // qx / tx: expanded rows of ONE matching problem (8 pieces of 16 bytes per row); both
@@ -158,7 +196,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ qx,
                                               int64_t part_row0, int64_t part_stride,
                                               unsigned q_block, unsigned split)
 {
-    __shared__ uint4 lds[2][256];
+    __shared__ uint4 lds[4][256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, r = lane & 31;
@@ -184,27 +222,43 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ qx,
 #pragma unroll
     for (int j = 0; j < QT; j++)
         m1[j] = m2[j] = MF_NONE;
+    f32x16 pend0, pend1; // keys awaiting their fold; "none" before the first tile
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        pend0[i] = pend1[i] = MF_NONE;
 
     // thread (wave w, lane l) stages piece 2 w + (l >> 5) of tile row l & 31 into slot
     // [w][l]: k-step s of the tile is then the 64 consecutive slots [s][0..63].
     const uint4 *__restrict__ src = tx + (t0 + r) * 8 + 2 * wave + h;
-    uint4 stage = make_uint4(0, 0, 0, 0);
-    if (n_tiles > 0)
-        stage = src[0];
-    for (int t = 0; t < n_tiles; t++) {
-        lds[t & 1][tid] = stage;
-        if (t + 1 < n_tiles)
-            stage = src[(int64_t)(t + 1) * 256];
-        __syncthreads();
+    if (n_tiles > 0) {
+        // LDS-DMA ring of four slots.  Every wave issues ONE load per tile, for tiles
+        // 0 .. n_tiles + 2 (the reads past the split stay inside the buffer's padding), so
+        // the count of loads in flight is the same at every wait.  Iteration t: wait for
+        // the wave's own piece of tile t + 1 (two younger loads stay in flight), barrier --
+        // tile t + 1 is now complete and every wave has taken its fragments of tile t,
+        // whose slot the load of tile t + 4 may overwrite.
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            load_to_lds(src + (int64_t)t * 256, &lds[t][wave * 64]);
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         i32x8 a[4];
 #pragma unroll
         for (int s = 0; s < 4; s++)
-            a[s] = frag(lds[t & 1][s * 64 + lane]);
-        const int valid = n - t * 32;
-        if (valid >= 32)
-            mfma_tile<K, QT, false>(a, b, c0, m1, m2, 32, h);
-        else
-            mfma_tile<K, QT, true>(a, b, c0, m1, m2, valid, h);
+            a[s] = frag(lds[0][s * 64 + lane]);
+        for (int t = 0; t + 1 < n_tiles; t++) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            load_to_lds(src + (int64_t)(t + 4) * 256, &lds[t & 3][wave * 64]);
+            mfma_tile<K, QT, false, true>(a, b, c0, m1, m2, pend0, pend1, 32, h,
+                                          &lds[(t + 1) & 3][lane]);
+        }
+        // the last tile (its fragments are already in registers) may be partial
+        const int valid = n - 32 * (n_tiles - 1);
+        mfma_tile<K, QT, true, false>(a, b, c0, m1, m2, pend0, pend1, valid, h, nullptr);
+        fold_pending<K, QT>(m1, m2, pend0, pend1, valid, h);
+        // no load may still be writing LDS when the workgroup gives it back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     // the two lane halves hold disjoint rows of the same tiles for the same queries
@@ -251,6 +305,34 @@ __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_kernel(
     knn_mfma_body<K, QT>(qx, tx, nq, nt, rows_per_split, part, 0, nq, nl % X, nl / X);
 }
 
+// A batch of independent matching problems (grid.z = frame), as knn_partial_frames_kernel:
+// frame f matches query rows [q_off[f], q_off[f+1]) against train rows [t_off[f],
+// t_off[f+1]).  qx / tx are the FP4 images of the rows from q_row0 / t_row0 on.
+template <int K, int QT>
+__global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_frames_kernel(
+    const uint4 *__restrict__ qx, const uint4 *__restrict__ tx, const int32_t *__restrict__ q_off,
+    const int32_t *__restrict__ t_off, int64_t q_row0, int64_t t_row0, int64_t total_nq,
+    uint32_t *__restrict__ part, int xcd_chunks)
+{
+    unsigned bx = blockIdx.x, by = blockIdx.y, f = blockIdx.z;
+    if (xcd_chunks) {
+        const unsigned X = gridDim.x, Y = gridDim.y, N = X * Y * gridDim.z;
+        const unsigned L = bx + X * (by + Y * f);
+        const unsigned base = N >> 3, rem = N & 7, c = L & 7;
+        const unsigned nl = c * base + min(c, rem) + (L >> 3); // bijective for any N
+        bx = nl % X;
+        const unsigned t = nl / X;
+        by = t % Y;
+        f = t / Y;
+    }
+    const int64_t q0 = q_off[f], nq = q_off[f + 1] - q0;
+    const int64_t t0 = t_off[f], nt = t_off[f + 1] - t0;
+    if ((int64_t)bx * (MF_WAVES * QT * 32) >= nq)
+        return;
+    knn_mfma_body<K, QT>(qx + 8 * (q0 - q_row0), tx + 8 * (t0 - t_row0), nq, nt,
+                         mfma_rows_per_split(nt, (int)gridDim.y), part, q0, total_nq, bx, by);
+}
+
 // ---- launchers ---------------------------------------------------------------------
 
 size_t knn_mfma_expanded_bytes(int64_t rows)
@@ -274,29 +356,80 @@ MfmaPlan knn_mfma_plan_splits(int64_t nq, int64_t nt, int q_tiles, int64_t split
     MfmaPlan p;
     p.q_tiles = q_tiles;
     p.q_blocks = (nq + 32 * q_tiles * MF_WAVES - 1) / (32 * q_tiles * MF_WAVES);
+    const int64_t min_splits = (nt + MF_MAX_ROWS_PER_SPLIT - 1) / MF_MAX_ROWS_PER_SPLIT;
+    if (splits < min_splits)
+        splits = min_splits;
     if (splits < 1)
         splits = 1;
-    int64_t rows = (nt + splits - 1) / splits;
-    rows = (rows + 31) & ~(int64_t)31;
-    if (rows < 32)
-        rows = 32;
-    if (rows > MF_MAX_ROWS_PER_SPLIT)
-        rows = MF_MAX_ROWS_PER_SPLIT;
-    p.rows_per_split = rows;
-    p.n_splits = (int)((nt + rows - 1) / rows);
+    p.rows_per_split = mfma_rows_per_split(nt, (int)splits);
+    p.n_splits = (int)((nt + p.rows_per_split - 1) / p.rows_per_split);
     if (p.n_splits < 1)
         p.n_splits = 1;
     p.part_bytes = (size_t)p.n_splits * 2 * (size_t)nq * sizeof(uint32_t);
     return p;
 }
 
-hipError_t knn_mfma_partial_launch(const MfmaPlan &p, const void *d_qx, int64_t nq,
-                                   const void *d_tx, int64_t nt, int k, uint32_t *d_part,
-                                   hipStream_t stream)
+// Splits: the (query block x split) grid should give every CU several workgroups (two are
+// resident per CU) while a split keeps at least 16 tiles, whose MFMAs hide the start-up
+// and the final key hand-over.
+static int64_t mfma_pick_splits(int64_t q_blocks_total, int64_t nt, int n_cus)
+{
+    int64_t splits = (5 * (int64_t)n_cus + q_blocks_total - 1) / q_blocks_total;
+    const int64_t by_rows = nt / 512;
+    if (splits > by_rows)
+        splits = by_rows;
+    return splits < 1 ? 1 : splits;
+}
+
+MfmaPlan knn_mfma_plan(int64_t nq, int64_t nt, int n_cus)
+{
+    const int qt = nq <= 2048 ? 2 : 4;
+    const int64_t q_blocks = (nq + 32 * qt * MF_WAVES - 1) / (32 * qt * MF_WAVES);
+    return knn_mfma_plan_splits(nq, nt, qt, mfma_pick_splits(q_blocks, nt, n_cus));
+}
+
+MfmaPlan knn_mfma_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int64_t total_nq,
+                              int n_cus)
+{
+    const int qt = max_nq <= 256 ? 2 : 4;
+    const int64_t q_blocks = (max_nq + 32 * qt * MF_WAVES - 1) / (32 * qt * MF_WAVES);
+    MfmaPlan p = knn_mfma_plan_splits(max_nq, max_nt, qt,
+                                      mfma_pick_splits(q_blocks * n_frames, max_nt, n_cus));
+    p.part_bytes = (size_t)p.n_splits * 2 * (size_t)total_nq * sizeof(uint32_t);
+    return p;
+}
+
+bool knn_mfma_pays(int64_t nq, int64_t nt)
+{
+    return nq >= 1024 && nt >= 1024 && nq * nt >= ((int64_t)1 << 23);
+}
+
+bool knn_mfma_pays_frames(int n_frames, int64_t max_nq, int64_t max_nt)
+{
+    return max_nq >= 128 && max_nt >= 256 && (int64_t)n_frames * max_nq * max_nt >= ((int64_t)1 << 23);
+}
+
+static hipError_t record(hipEvent_t *events, int i, hipStream_t stream)
+{
+    return events ? hipEventRecord(events[i], stream) : hipSuccess;
+}
+
+hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, const void *d_train,
+                           int64_t nt, int k, int32_t index_base, void *d_qx, void *d_tx,
+                           uint32_t *d_part, int32_t *d_out_idx, int32_t *d_out_dist,
+                           uint8_t *d_keep, float ratio, hipStream_t stream, hipEvent_t *events)
 {
     if (p.n_splits < 1 || p.n_splits > 65535 || p.rows_per_split > MF_MAX_ROWS_PER_SPLIT ||
-        (p.rows_per_split & 31) != 0 || (uint64_t)p.q_blocks * (uint64_t)p.n_splits >= (1ull << 31))
+        (p.rows_per_split & 31) != 0 || p.rows_per_split * (int64_t)p.n_splits < nt ||
+        (uint64_t)p.q_blocks * (uint64_t)p.n_splits >= (1ull << 31))
         return hipErrorInvalidValue;
+    hipError_t e;
+    if ((e = knn_mfma_expand_launch(d_query, nq, d_qx, stream)) != hipSuccess)
+        return e;
+    if ((e = knn_mfma_expand_launch(d_train, nt, d_tx, stream)) != hipSuccess)
+        return e;
+    if ((e = record(events, 0, stream)) != hipSuccess)
+        return e;
     dim3 grid((unsigned)p.q_blocks, (unsigned)p.n_splits);
     const uint4 *q4 = (const uint4 *)d_qx, *t4 = (const uint4 *)d_tx;
 #define POSEHIP_MF_LAUNCH(KK, QQ)                                                               \
@@ -310,14 +443,72 @@ hipError_t knn_mfma_partial_launch(const MfmaPlan &p, const void *d_qx, int64_t 
         POSEHIP_MF_LAUNCH(2, 2);
     else if (p.q_tiles == 2)
         POSEHIP_MF_LAUNCH(1, 2);
-    else if (p.q_tiles == 8 && k == 2)
-        POSEHIP_MF_LAUNCH(2, 8);
-    else if (p.q_tiles == 8)
-        POSEHIP_MF_LAUNCH(1, 8);
     else
         return hipErrorInvalidValue;
 #undef POSEHIP_MF_LAUNCH
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess)
+        return e;
+    if ((e = record(events, 1, stream)) != hipSuccess)
+        return e;
+    if ((e = knn_merge_launch(d_part, nq, p.n_splits, p.rows_per_split, k, index_base, d_out_idx,
+                              d_out_dist, d_keep, ratio, stream)) != hipSuccess)
+        return e;
+    if ((e = record(events, 2, stream)) != hipSuccess)
+        return e;
+    return record(events, 3, stream);
+}
+
+hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const int32_t *d_q_off,
+                                  int64_t q_begin, int64_t q_end, const void *d_train,
+                                  const int32_t *d_t_off, int64_t t_begin, int64_t t_end,
+                                  int n_frames, int k, void *d_qx, void *d_tx, uint32_t *d_part,
+                                  int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,
+                                  float ratio, hipStream_t stream, hipEvent_t *events,
+                                  bool uniform_frames)
+{
+    if (p.n_splits < 1 || p.n_splits > 65535 || n_frames < 1 || n_frames > 65535 ||
+        p.q_blocks < 1 || p.q_blocks > 0x7FFFFFFF)
+        return hipErrorInvalidValue;
+    const int xcd = uniform_frames && n_frames >= 8 &&
+                            (uint64_t)p.q_blocks * (uint64_t)p.n_splits * (uint64_t)n_frames < (1ull << 31)
+                        ? 1 : 0;
+    hipError_t e;
+    if ((e = knn_mfma_expand_launch((const uint8_t *)d_query + q_begin * 32, q_end - q_begin, d_qx,
+                                    stream)) != hipSuccess)
+        return e;
+    if ((e = knn_mfma_expand_launch((const uint8_t *)d_train + t_begin * 32, t_end - t_begin, d_tx,
+                                    stream)) != hipSuccess)
+        return e;
+    if ((e = record(events, 0, stream)) != hipSuccess)
+        return e;
+    dim3 grid((unsigned)p.q_blocks, (unsigned)p.n_splits, (unsigned)n_frames);
+    const uint4 *q4 = (const uint4 *)d_qx, *t4 = (const uint4 *)d_tx;
+#define POSEHIP_MF_LAUNCH(KK, QQ)                                                               \
+    knn_mfma_frames_kernel<KK, QQ><<<grid, MF_WAVES * 64, 0, stream>>>(                         \
+        q4, t4, d_q_off, d_t_off, q_begin, t_begin, q_end, d_part, xcd)
+    if (p.q_tiles == 4 && k == 2)
+        POSEHIP_MF_LAUNCH(2, 4);
+    else if (p.q_tiles == 4)
+        POSEHIP_MF_LAUNCH(1, 4);
+    else if (p.q_tiles == 2 && k == 2)
+        POSEHIP_MF_LAUNCH(2, 2);
+    else if (p.q_tiles == 2)
+        POSEHIP_MF_LAUNCH(1, 2);
+    else
+        return hipErrorInvalidValue;
+#undef POSEHIP_MF_LAUNCH
+    if ((e = hipGetLastError()) != hipSuccess)
+        return e;
+    if ((e = record(events, 1, stream)) != hipSuccess)
+        return e;
+    const int64_t max_nq = p.q_blocks * (32 * p.q_tiles * MF_WAVES);
+    if ((e = knn_merge_frames_launch(d_part, d_q_off, d_t_off, q_end, max_nq, n_frames, p.n_splits,
+                                     -1, k, d_out_idx, d_out_dist, d_keep, ratio, stream)) !=
+        hipSuccess)
+        return e;
+    if ((e = record(events, 2, stream)) != hipSuccess)
+        return e;
+    return record(events, 3, stream);
 }
 
 } // namespace posehip

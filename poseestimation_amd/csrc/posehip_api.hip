@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "knn_hamming.h"
+#include "knn_mfma.h"
 #include "ransac_epnp.h"
 #include "posehip.h"
 
@@ -122,6 +123,7 @@ struct Context {
     hipStream_t stream = nullptr;
     DevBuf part;   // per-split keys of the distance kernel
     DevBuf part2;  // same, for the swapped pass of the cross-check
+    DevBuf xq, xt; // FP4 images of the query / train rows (matrix-core path)
     DevBuf best;   // cross-check per-query 64-bit keys
     DevBuf tmp_i;  // cross-check per-train nearest query index
     DevBuf tmp_d;  // cross-check per-train nearest query distance
@@ -145,6 +147,8 @@ struct Context {
     hipEvent_t scratch_ev = nullptr;
     RansacOverlap pnp_overlap = {nullptr, nullptr, nullptr}; // side stream of batched RANSAC
     bool profiling = false;                 // record events around the distance kernel
+    int knn_path = 0;                       // 0: by size, 1: popcount kernel only, 2: matrix cores only
+    int last_path = 0;                      // distance kernel of the last k-NN call: 0 VALU, 1 MFMA
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
 };
@@ -231,6 +235,21 @@ ph_status knn_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t n
         return fail(PH_ERR_INVALID_ARG, "descriptor buffers must be 16-byte aligned");
     if ((int64_t)base + nt - 1 > 0x7FFFFFFF)
         return fail(PH_ERR_TOO_LARGE, "train_index_base + nt exceeds the 32-bit index range");
+    hipEvent_t *ev = g_ctx.profiling ? g_ctx.ev : nullptr;
+    if (g_ctx.knn_path == 2 || (g_ctx.knn_path == 0 && knn_mfma_pays(nq, nt))) {
+        const MfmaPlan mp = knn_mfma_plan(nq, nt, g_ctx.n_cus);
+        ph_status gs = scratch_guard(st);
+        if (gs != PH_OK)
+            return gs;
+        PH_HIP(part.reserve(mp.part_bytes));
+        PH_HIP(g_ctx.xq.reserve(knn_mfma_expanded_bytes(nq)));
+        PH_HIP(g_ctx.xt.reserve(knn_mfma_expanded_bytes(nt)));
+        PH_HIP(knn_mfma_launch(mp, d_q, nq, d_t, nt, k, base, g_ctx.xq.p, g_ctx.xt.p,
+                               (uint32_t *)part.p, d_idx, d_dist, d_keep, ratio, st, ev));
+        g_ctx.ev_valid = ev != nullptr;
+        g_ctx.last_path = 1;
+        return PH_OK;
+    }
     KnnPlan plan = knn_plan(nq, nt, g_ctx.n_cus);
     if (plan.rows_per_split * (int64_t)plan.n_splits < nt)
         return fail(PH_ERR_TOO_LARGE, "train set of %lld rows is too large for one call", (long long)nt);
@@ -238,7 +257,7 @@ ph_status knn_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t n
     if (gs != PH_OK)
         return gs;
     PH_HIP(part.reserve(plan.part_bytes));
-    hipEvent_t *ev = g_ctx.profiling ? g_ctx.ev : nullptr;
+    g_ctx.last_path = 0;
     PH_HIP(knn_launch(plan, d_q, nq, d_t, nt, k, base, (uint32_t *)part.p, d_idx, d_dist, d_keep,
                       ratio, st, ev));
     g_ctx.ev_valid = ev != nullptr;
@@ -361,7 +380,7 @@ ph_status check_host_args(const uint8_t *q, int nq, size_t q_step, const uint8_t
 struct FrameBatch {
     int64_t max_nq = 0, max_nt = 0;
     bool uniform = true; // every frame has max_nq query rows and max_nt train rows
-    int64_t q_begin = 0, q_end = 0, t_end = 0;
+    int64_t q_begin = 0, q_end = 0, t_begin = 0, t_end = 0;
     const int32_t *d_q_off = nullptr, *d_t_off = nullptr; // device copies of the tables
 };
 
@@ -389,6 +408,7 @@ ph_status check_frames(const int32_t *q_offsets, const int32_t *t_offsets, int n
             fb.uniform = false;
     fb.q_begin = q_offsets[0];
     fb.q_end = q_offsets[n_frames];
+    fb.t_begin = t_offsets[0];
     fb.t_end = t_offsets[n_frames];
     return PH_OK;
 }
@@ -585,7 +605,7 @@ void ph_shutdown(void)
     }
     g_dbs.clear();
     DevBuf *all[] = {&g_ctx.part,  &g_ctx.part2, &g_ctx.best,   &g_ctx.tmp_i,
-                     &g_ctx.tmp_d, &g_ctx.d_in,  &g_ctx.pnp_idx};
+                     &g_ctx.tmp_d, &g_ctx.d_in,  &g_ctx.pnp_idx, &g_ctx.xq,   &g_ctx.xt};
     for (DevBuf *b : all)
         b->release();
     g_ctx.h_in.release();
@@ -638,6 +658,17 @@ ph_status ph_set_profiling(int enable)
     g_ctx.ev_valid = false;
     return PH_OK;
 }
+
+ph_status ph_knn_set_path(int mode)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (mode < 0 || mode > 2)
+        return fail(PH_ERR_INVALID_ARG, "k-NN path must be 0 (by size), 1 (popcount) or 2 (matrix cores)");
+    g_ctx.knn_path = mode;
+    return PH_OK;
+}
+
+int ph_knn_last_path(void) { return g_ctx.last_path; }
 
 ph_status ph_knn_last_timing_overhead(float *empty_interval_ms)
 {
@@ -706,6 +737,66 @@ ph_status ph_knn_hamming256_dev(const void *d_query, int64_t nq, const void *d_t
                           d_keep, ratio, g_ctx.part, pick_stream(stream));
 }
 
+// One side (query or train) of a batch of frames: device rows, HOST offset table, the
+// row range the table spans and the longest frame.
+struct FrameSide {
+    const void *d_rows;
+    const int32_t *offsets;
+    int64_t begin, end, max_rows;
+};
+
+// Device copies of the last batch's tables, in the order of knn_frames_locked's (q, t)
+// arguments (the cross-check passes its train side as q), and their ring slot.
+const int32_t *g_frames_d_q_off = nullptr, *g_frames_d_t_off = nullptr;
+Context::OffsetSlot *g_frames_slot = nullptr;
+
+// k-NN of every frame's q rows among its t rows, into outputs indexed by q row; the
+// caller holds g_mu.  Picks the matrix-core or the popcount kernel by size.
+ph_status knn_frames_locked(const FrameSide &q, const FrameSide &t, int n_frames, bool uniform,
+                            int k, DevBuf &part, int32_t *d_out_idx, int32_t *d_out_dist,
+                            uint8_t *d_keep, float ratio, hipStream_t st, hipEvent_t *ev)
+{
+    ph_status s;
+    FrameBatch fb; // carries the device tables out of upload_frame_tables
+    Context::OffsetSlot *slot = nullptr;
+    const bool mfma = g_ctx.knn_path == 2 ||
+                      (g_ctx.knn_path == 0 && knn_mfma_pays_frames(n_frames, q.max_rows, t.max_rows));
+    MfmaPlan mp;
+    KnnPlan plan;
+    if (mfma) {
+        mp = knn_mfma_plan_frames(n_frames, q.max_rows, t.max_rows, q.end, g_ctx.n_cus);
+    } else {
+        plan = knn_plan_frames(n_frames, q.max_rows, t.max_rows, q.end, g_ctx.n_cus);
+        if (frame_rows_per_split(t.max_rows, plan) * (int64_t)plan.n_splits < t.max_rows)
+            return fail(PH_ERR_TOO_LARGE, "set of %lld rows is too large for one call",
+                        (long long)t.max_rows);
+    }
+    if ((s = scratch_guard(st)) != PH_OK)
+        return s;
+    PH_HIP(part.reserve(mfma ? mp.part_bytes : plan.part_bytes));
+    if (mfma) {
+        PH_HIP(g_ctx.xq.reserve(knn_mfma_expanded_bytes(q.end - q.begin)));
+        PH_HIP(g_ctx.xt.reserve(knn_mfma_expanded_bytes(t.end - t.begin)));
+    }
+    if ((s = upload_frame_tables(q.offsets, t.offsets, n_frames, st, fb, slot)) != PH_OK)
+        return s;
+    if (mfma)
+        PH_HIP(knn_mfma_frames_launch(mp, q.d_rows, fb.d_q_off, q.begin, q.end, t.d_rows,
+                                      fb.d_t_off, t.begin, t.end, n_frames, k, g_ctx.xq.p,
+                                      g_ctx.xt.p, (uint32_t *)part.p, d_out_idx, d_out_dist,
+                                      d_keep, ratio, st, ev, uniform));
+    else
+        PH_HIP(knn_frames_launch(plan, q.d_rows, fb.d_q_off, t.d_rows, fb.d_t_off, n_frames, q.end,
+                                 k, (uint32_t *)part.p, d_out_idx, d_out_dist, d_keep, ratio, st,
+                                 ev, uniform));
+    PH_HIP(hipEventRecord(slot->done, st));
+    g_ctx.last_path = mfma ? 1 : 0;
+    g_frames_d_q_off = fb.d_q_off;
+    g_frames_d_t_off = fb.d_t_off;
+    g_frames_slot = slot;
+    return PH_OK;
+}
+
 ph_status ph_knn_hamming256_frames_dev(const void *d_query, const int32_t *q_offsets,
                                        const void *d_train, const int32_t *t_offsets,
                                        int n_frames, int k, int32_t *d_out_idx,
@@ -738,21 +829,12 @@ ph_status ph_knn_hamming256_frames_dev(const void *d_query, const int32_t *q_off
     }
     if (((uintptr_t)d_query & 15) || ((uintptr_t)d_train & 15))
         return fail(PH_ERR_INVALID_ARG, "descriptor buffers must be 16-byte aligned");
-    const KnnPlan plan = knn_plan_frames(n_frames, fb.max_nq, fb.max_nt, fb.q_end, g_ctx.n_cus);
-    if (frame_rows_per_split(fb.max_nt, plan) * (int64_t)plan.n_splits < fb.max_nt)
-        return fail(PH_ERR_TOO_LARGE, "train set of %lld rows is too large for one call",
-                    (long long)fb.max_nt);
-    if ((s = scratch_guard(st)) != PH_OK)
-        return s;
-    PH_HIP(g_ctx.part.reserve(plan.part_bytes));
-    Context::OffsetSlot *slot = nullptr;
-    if ((s = upload_frame_tables(q_offsets, t_offsets, n_frames, st, fb, slot)) != PH_OK)
-        return s;
     hipEvent_t *ev = g_ctx.profiling ? g_ctx.ev : nullptr;
-    PH_HIP(knn_frames_launch(plan, d_query, fb.d_q_off, d_train, fb.d_t_off, n_frames, fb.q_end, k,
-                             (uint32_t *)g_ctx.part.p, d_out_idx, d_out_dist, d_keep, ratio, st,
-                             ev, fb.uniform));
-    PH_HIP(hipEventRecord(slot->done, st));
+    FrameSide q = {d_query, q_offsets, fb.q_begin, fb.q_end, fb.max_nq};
+    FrameSide t = {d_train, t_offsets, fb.t_begin, fb.t_end, fb.max_nt};
+    if ((s = knn_frames_locked(q, t, n_frames, fb.uniform, k, g_ctx.part, d_out_idx, d_out_dist,
+                               d_keep, ratio, st, ev)) != PH_OK)
+        return s;
     g_ctx.ev_valid = ev != nullptr;
     return PH_OK;
 }
@@ -783,30 +865,27 @@ ph_status ph_match_crosscheck_hamming256_frames_dev(const void *d_query, const i
     }
     if (((uintptr_t)d_query & 15) || ((uintptr_t)d_train & 15))
         return fail(PH_ERR_INVALID_ARG, "descriptor buffers must be 16-byte aligned");
-    // Roles swapped: every train row finds its nearest query row of its own frame.
-    const KnnPlan plan = knn_plan_frames(n_frames, fb.max_nt, fb.max_nq, fb.t_end, g_ctx.n_cus);
-    if (fb.max_nq > 0 &&
-        frame_rows_per_split(fb.max_nq, plan) * (int64_t)plan.n_splits < fb.max_nq)
-        return fail(PH_ERR_TOO_LARGE, "query set of %lld rows is too large for one call",
-                    (long long)fb.max_nq);
     if ((s = scratch_guard(st)) != PH_OK)
         return s;
-    PH_HIP(g_ctx.part2.reserve(plan.part_bytes));
     PH_HIP(g_ctx.tmp_i.reserve((size_t)fb.t_end * sizeof(int32_t)));
     PH_HIP(g_ctx.tmp_d.reserve((size_t)fb.t_end * sizeof(int32_t)));
     PH_HIP(g_ctx.best.reserve((size_t)fb.q_end * sizeof(unsigned long long)));
-    Context::OffsetSlot *slot = nullptr;
-    if ((s = upload_frame_tables(q_offsets, t_offsets, n_frames, st, fb, slot)) != PH_OK)
+    // Roles swapped: every train row finds its nearest query row of its own frame (so the
+    // device tables come back as g_frames_d_q_off = train offsets, _t_off = query offsets).
+    FrameSide q = {d_query, q_offsets, fb.q_begin, fb.q_end, fb.max_nq};
+    FrameSide t = {d_train, t_offsets, fb.t_begin, fb.t_end, fb.max_nt};
+    if ((s = knn_frames_locked(t, q, n_frames, fb.uniform, 1, g_ctx.part2,
+                               (int32_t *)g_ctx.tmp_i.p, (int32_t *)g_ctx.tmp_d.p, nullptr, 0.f,
+                               st, nullptr)) != PH_OK)
         return s;
-    PH_HIP(knn_frames_launch(plan, d_train, fb.d_t_off, d_query, fb.d_q_off, n_frames, fb.t_end, 1,
-                             (uint32_t *)g_ctx.part2.p, (int32_t *)g_ctx.tmp_i.p,
-                             (int32_t *)g_ctx.tmp_d.p, nullptr, 0.f, st, nullptr, fb.uniform));
+    // (the tables' ring slot stays busy until the resolve kernels below have run:
+    // same stream, and the next call that reuses the slot waits for its event)
     PH_HIP(crosscheck_resolve_frames_launch((const int32_t *)g_ctx.tmp_i.p,
-                                            (const int32_t *)g_ctx.tmp_d.p, fb.d_q_off, fb.d_t_off,
-                                            n_frames, fb.max_nt, fb.q_begin, fb.q_end,
-                                            (unsigned long long *)g_ctx.best.p, d_out_idx,
-                                            d_out_dist, st));
-    PH_HIP(hipEventRecord(slot->done, st));
+                                            (const int32_t *)g_ctx.tmp_d.p, g_frames_d_t_off,
+                                            g_frames_d_q_off, n_frames, fb.max_nt, fb.q_begin,
+                                            fb.q_end, (unsigned long long *)g_ctx.best.p,
+                                            d_out_idx, d_out_dist, st));
+    PH_HIP(hipEventRecord(g_frames_slot->done, st));
     return PH_OK;
 }
 

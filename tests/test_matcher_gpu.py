@@ -15,6 +15,23 @@ pytestmark = pytest.mark.gpu
 INT_MAX = 2147483647
 
 
+@pytest.fixture(params=["by_size", "matrix_cores"], autouse=True)
+def knn_path(request, posehip):
+    """Every test runs twice: with the library choosing the distance kernel by problem size
+    (small problems take the popcount kernel, large ones the matrix cores) and with the
+    matrix-core kernel forced, so that the small, ragged and degenerate cases reach it."""
+    mode = {"by_size": 0, "popcount": 1, "matrix_cores": 2}[request.param]
+    posehip.check(posehip.load().ph_knn_set_path(mode))
+    yield request.param
+    posehip.load().ph_knn_set_path(0)
+
+
+# large problems go to the matrix cores by size: these keep the popcount kernel's long
+# streams (lazy key update, several key ranges) covered as well
+all_paths = pytest.mark.parametrize("knn_path", ["by_size", "matrix_cores", "popcount"],
+                                    indirect=True)
+
+
 def gpu_knn(lib, q, t, k):
     nq, nt = q.shape[0], t.shape[0]
     idx = np.full((nq, k), 12345, np.int32)
@@ -198,6 +215,7 @@ def gpu_knn_dev(lib, d_q, d_t, k, base=0, ratio=None):
     return idx, dist, keep
 
 
+@all_paths
 def test_full_size_config_bit_exact(posehip):
     """BASELINE configs[1] at full size: 10k x 10k, k=2 + ratio, every row checked."""
     q = datagen.random_descriptors(10000, 2)
@@ -210,6 +228,7 @@ def test_full_size_config_bit_exact(posehip):
     assert np.nonzero(keep.cpu().numpy())[0].tolist() == kept
 
 
+@all_paths
 def test_long_train_stream_sampled(posehip):
     """200k queries x 60k train rows (the lazy key-update path, several rows per wave
     slice): 512 sampled query rows checked against the oracle, plus properties that
@@ -302,6 +321,7 @@ def test_crosscheck_dev(posehip):
     assert got == orc.match(q, t, cross_check=True)
 
 
+@all_paths
 def test_train_set_beyond_one_key_range(posehip):
     """More train rows than one 22-bit split index holds (4 194 304): the split cap and
     the cross-split tie-break (equal rows planted on both sides of the boundary)."""
@@ -338,6 +358,7 @@ def test_index_base_and_overflow_guard(posehip):
     assert st == 5  # PH_ERR_TOO_LARGE: base + nt would not fit an int32 index
 
 
+@all_paths
 def test_long_stream_k1_and_lazy_path(posehip):
     """k = 1 on a shape that takes the no-split, lazy-update plan (1.1M queries): sampled
     rows against the oracle; planted exact copies must be found at their lowest index."""
@@ -459,6 +480,7 @@ def test_frames_video_stream(posehip):
         assert np.array_equal(dist[off[f]:off[f + 1]], rd)
 
 
+@all_paths
 def test_frames_equal_single_calls_at_bench_shape(posehip):
     """Four 10k x 10k frames in one launch == four single-frame calls (bit for bit)."""
     import torch

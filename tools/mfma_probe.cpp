@@ -54,6 +54,8 @@ static std::vector<uint32_t> make_rows(int64_t n, int pool, int flips, uint32_t 
     return out;
 }
 
+static int g_ring = 1;
+
 static int check(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int k, int pool, int flips)
 {
     auto q = make_rows(nq, pool, flips, 1 + (uint32_t)nq), t = make_rows(nt, pool, flips, 7 + (uint32_t)nt);
@@ -72,6 +74,7 @@ static int check(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int k, int
     CK(hipMemcpy(dq, q.data(), nq * 32, hipMemcpyHostToDevice));
     CK(hipMemcpy(dt, t.data(), nt * 32, hipMemcpyHostToDevice));
     MfmaPlan p = knn_mfma_plan_splits(nq, nt, q_tiles, splits);
+    p.ring = g_ring;
     CK(hipMalloc(&dpart, p.part_bytes));
     CK(knn_mfma_expand_launch(dq, nq, dqx, 0));
     CK(knn_mfma_expand_launch(dt, nt, dtx, 0));
@@ -119,7 +122,7 @@ static int check(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int k, int
             bad++;
         }
     }
-    printf("check nq=%lld nt=%lld splits=%d rows/split=%lld q_tiles=%d k=%d pool=%d flips=%d: %s (%d bad)\n",
+    printf("ring=%d check nq=%lld nt=%lld splits=%d rows/split=%lld q_tiles=%d k=%d pool=%d flips=%d: %s (%d bad)\n",
            (long long)nq, (long long)nt, p.n_splits, (long long)p.rows_per_split, q_tiles, k, pool,
            flips, bad ? "FAIL" : "ok", bad);
     fflush(stdout);
@@ -143,6 +146,7 @@ static void timeit(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int reps
     CK(hipMemcpy(dq, q.data(), nq * 32, hipMemcpyHostToDevice));
     CK(hipMemcpy(dt, t.data(), nt * 32, hipMemcpyHostToDevice));
     MfmaPlan p = knn_mfma_plan_splits(nq, nt, q_tiles, splits);
+    p.ring = g_ring;
     CK(hipMalloc(&dpart, p.part_bytes));
     hipEvent_t e0, e1, e2;
     CK(hipEventCreate(&e0));
@@ -166,9 +170,9 @@ static void timeit(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int reps
         }
     }
     const double evals = (double)nq * (double)nt;
-    printf("time nq=%lld nt=%lld splits=%d rows/split=%lld q_tiles=%d grid=%lldx%d: expand %.1f us, "
+    printf("ring=%d time nq=%lld nt=%lld splits=%d rows/split=%lld q_tiles=%d grid=%lldx%d: expand %.1f us, "
            "kernel %.1f us = %.3e evals/s = %.2f PFLOP/s fp4\n",
-           (long long)nq, (long long)nt, p.n_splits, (long long)p.rows_per_split, q_tiles,
+           g_ring, (long long)nq, (long long)nt, p.n_splits, (long long)p.rows_per_split, q_tiles,
            (long long)p.q_blocks, p.n_splits, best_x * 1e3, best_k * 1e3, evals / (best_k * 1e-3),
            evals * 512 / (best_k * 1e-3) / 1e15);
     fflush(stdout);
@@ -187,21 +191,30 @@ int main(int argc, char **argv)
         return 0;
     }
     int bad = 0;
-    for (int qt : {4, 2, 8})
-        for (int k : {2, 1}) {
-            bad += check(700, 3001, 3, qt, k, 16, 3);
-            bad += check(33, 40, 1, qt, k, 4, 1);
-            bad += check(1, 1, 1, qt, k, 1, 0);
-            bad += check(513, 31, 1, qt, k, 1, 0);
-            bad += check(300, 2000, 1, qt, k, 1, 0); // all distances equal except row 3
-            bad += check(1500, 5000, 7, qt, k, 1 << 20, 0);
-        }
-    bad += check(64, 40000, 1, 4, 2, 8, 2); // two splits of 32768 / 7232 rows: 1024 tiles
+    for (int ring : {1, 0}) {
+        g_ring = ring;
+        for (int qt : {4, 2, 8})
+            for (int k : {2, 1}) {
+                bad += check(700, 3001, 3, qt, k, 16, 3);
+                bad += check(33, 40, 1, qt, k, 4, 1);
+                bad += check(1, 1, 1, qt, k, 1, 0);
+                bad += check(513, 31, 1, qt, k, 1, 0);
+                bad += check(300, 2000, 1, qt, k, 1, 0); // all distances equal except row 3
+                bad += check(1500, 5000, 7, qt, k, 1 << 20, 0);
+                bad += check(200, 64, 1, qt, k, 2, 1);
+                bad += check(200, 65, 1, qt, k, 2, 1);
+                bad += check(200, 97, 2, qt, k, 2, 1);
+            }
+        bad += check(64, 40000, 1, 4, 2, 8, 2); // two splits of 32768 / 7232 rows: 1024 tiles
+    }
     printf(bad ? "PROBE FAILED\n" : "PROBE OK\n");
     if (bad)
         return 1;
-    for (int qt : {4, 8, 2})
-        for (int splits : {1, 2, 4, 8})
-            timeit(163840, 10000, splits, qt, 5);
+    for (int ring : {1, 0}) {
+        g_ring = ring;
+        for (int qt : {4, 8, 2})
+            for (int splits : {1, 2, 4, 8})
+                timeit(163840, 10000, splits, qt, 5);
+    }
     return 0;
 }
