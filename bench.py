@@ -284,48 +284,99 @@ def main():
         event_ms = float(np.mean(ov))
         kernel_ms = float(np.mean(ks)) - event_ms
         merge_ms = float(np.mean(ms)) - event_ms
+        mfma_path = lib.ph_knn_last_path() == 1
+        prepass_ms = 0.0
+        if mfma_path:
+            _lib.check(lib.ph_set_profiling(1))
+            pp = []
+            for r in range(12):
+                for _ in range(3):
+                    step()
+                _lib.check(lib.ph_knn_last_prepass_timing(C.byref(a)))
+                if r >= 2:
+                    pp.append(a.value)
+            _lib.check(lib.ph_set_profiling(0))
+            prepass_ms = float(np.mean(pp)) - event_ms
         peak_ops = C.c_double(0)
         _lib.check(lib.ph_valu_popcount_peak(4000, C.byref(peak_ops)))
         peak_evals = peak_ops.value / 16.0
         achieved = float(nq) * nt * F / (kernel_ms * 1e-3)
+        kernel_name = "knn_mfma_frames_kernel" if mfma_path else "knn_partial_frames_kernel"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and (nq, nt, F) == (10000, 10000, 16):
             try:
-                traffic = json.load(open(tpath)).get("knn_partial_frames_kernel_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(kernel_name + "_bytes_per_launch")
             except Exception:
                 traffic = None
+
+        def timed(fn_step, n):
+            for _ in range(3):
+                fn_step()
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            for _ in range(n):
+                fn_step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - p0) / n
+
         # the same frames as one call each (outside the timed region above)
-        for _ in range(3):
-            step_per_call()
-        torch.cuda.synchronize()
         pc_steps = max(5, min(args.steps, 30))
-        p0 = time.perf_counter()
-        for _ in range(pc_steps):
-            step_per_call()
-        torch.cuda.synchronize()
-        per_call_s = (time.perf_counter() - p0) / pc_steps
+        per_call_s = timed(step_per_call, pc_steps)
         per_call = {"value": float(nq) * nt * F / per_call_s, "unit": "Hamming evals/s",
                     "us_per_frame": per_call_s / F * 1e6, "steps": pc_steps,
                     "what": f"the same {F} frames, one ph_knn_hamming256_dev call per frame, rank 0"}
-        roofline = {
-            "bound": "valu",
-            "bound_note": "integer VALU issue (xor + popcount): the path is neither HBM- nor "
-                          "MFMA-bound; hbm_algorithmic_GBps and traffic show how far it is from HBM",
-            "kernel": "knn_partial_frames_kernel",
-            "achieved": achieved / 1e12,
-            "peak": peak_evals / 1e12,
-            "unit": "Teval/s",
-            "frac": achieved / peak_evals,
-            "traffic": traffic,
-            "work_per_launch": f"{F} frames x {nq}x{nt} Hamming-256 evals (16 VALU lane-ops each)",
-            "kernel_ms": kernel_ms,
-            "merge_kernel_ms": merge_ms,
-            "event_interval_overhead_ms": event_ms,
-            "peak_source": "measured live: v_xor_b32+v_bcnt_u32_b32 mix, 8 waves/SIMD, /16",
-            "peak_spec": 256 * 64 * 2.4e9 / 16 / 1e12,
-            "hbm_algorithmic_GBps": 32.0 * (nq + nt) * F / (kernel_ms * 1e-3) / 1e9,
-        }
+        # and the same batched step on the other distance kernel (xor + popcount on the VALU)
+        popcount = None
+        if mfma_path:
+            _lib.check(lib.ph_knn_set_path(1))
+            pop_s = timed(step, pc_steps)
+            _lib.check(lib.ph_knn_set_path(0))
+            popcount = {"value": float(nq) * nt * F / pop_s, "unit": "Hamming evals/s",
+                        "ms_per_step": pop_s * 1e3,
+                        "valu_peak_evals_per_s": peak_evals,
+                        "what": "the same step with ph_knn_set_path(1): the popcount kernel "
+                                "(v_xor_b32 + v_bcnt_u32_b32), whose ceiling is the VALU peak"}
+        if mfma_path:
+            flops = 512.0 * nq * nt * F  # 256 multiply-adds per pair
+            peak_tflops = 10000.0        # dense FP4 MFMA peak of MI355X
+            roofline = {
+                "bound": "mfma",
+                "kernel": kernel_name,
+                "achieved": flops / (kernel_ms * 1e-3) / 1e12,
+                "peak": peak_tflops,
+                "unit": "TFLOP/s",
+                "frac": flops / (kernel_ms * 1e-3) / 1e12 / peak_tflops,
+                "traffic": traffic,
+                "work_per_launch": f"{F} frames x {nq}x{nt} pairs x 256 FP4 multiply-adds "
+                                   f"(v_mfma_scale_f32_32x32x64_f8f6f4, exact in fp32)",
+                "evals_per_s": achieved,
+                "kernel_ms": kernel_ms,
+                "prepass_ms": prepass_ms,
+                "merge_kernel_ms": merge_ms,
+                "event_interval_overhead_ms": event_ms,
+                "peak_source": "dense FP4 MFMA peak (~10 PFLOP/s at 2.4 GHz)",
+                "hbm_algorithmic_GBps": 128.0 * (nq + nt) * F / (kernel_ms * 1e-3) / 1e9,
+            }
+        else:
+            roofline = {
+                "bound": "valu",
+                "bound_note": "integer VALU issue (xor + popcount): the path is neither HBM- nor "
+                              "MFMA-bound; hbm_algorithmic_GBps and traffic show how far it is from HBM",
+                "kernel": kernel_name,
+                "achieved": achieved / 1e12,
+                "peak": peak_evals / 1e12,
+                "unit": "Teval/s",
+                "frac": achieved / peak_evals,
+                "traffic": traffic,
+                "work_per_launch": f"{F} frames x {nq}x{nt} Hamming-256 evals (16 VALU lane-ops each)",
+                "kernel_ms": kernel_ms,
+                "merge_kernel_ms": merge_ms,
+                "event_interval_overhead_ms": event_ms,
+                "peak_source": "measured live: v_xor_b32+v_bcnt_u32_b32 mix, 8 waves/SIMD, /16",
+                "peak_spec": 256 * 64 * 2.4e9 / 16 / 1e12,
+                "hbm_algorithmic_GBps": 32.0 * (nq + nt) * F / (kernel_ms * 1e-3) / 1e9,
+            }
 
         cpu = None
         if not args.no_cpu_baseline:
@@ -375,7 +426,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (xor + popcount)",
+            "dtype": "fp4 e2m1 x fp4 -> f32 (exact integers)" if mfma_path else "u32 (xor + popcount)",
             "data": "synthetic",
             "config": {
                 "workload": f"{nq}x{nt} ORB-descriptor kNN k=2 + ratio {args.ratio} per frame "
@@ -386,6 +437,7 @@ def main():
             },
             "us_per_frame": elapsed / args.steps / F * 1e6,
             "per_call": per_call,
+            "popcount_kernel": popcount,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "ransac_epnp": ransac,

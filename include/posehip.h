@@ -267,6 +267,8 @@ ph_status ph_ransac_epnp_hypotheses_batched_dev(const float *d_obj, const float 
  * for the last such call and returns both durations in milliseconds. */
 ph_status ph_set_profiling(int enable);
 ph_status ph_knn_last_timing(float *distance_kernel_ms, float *merge_kernel_ms);
+/* Duration of the bit -> FP4 pre-pass of that call (0 when it ran the popcount kernel). */
+ph_status ph_knn_last_prepass_timing(float *prepass_ms);
 /* Duration of an empty event-to-event interval recorded right after that call:
  * the fixed cost the two figures above include on top of the kernels' own time. */
 ph_status ph_knn_last_timing_overhead(float *empty_interval_ms);
@@ -275,7 +277,8 @@ ph_status ph_knn_last_timing_overhead(float *empty_interval_ms);
  * matrix-core kernel (descriptor bits as FP4 +-4, Hamming distance from the dot
  * product), bit-identical in their results.  mode 0 (default) picks by problem
  * size, 1 always takes the popcount kernel, 2 always the matrix cores.  May be
- * called before ph_init; ph_shutdown resets it to 0.  ph_knn_last_path: which
+ * called before ph_init; ph_shutdown resets it to 0.  ph_init also reads the
+ * environment variable POSEHIP_KNN_PATH ("popcount" / "matrix").  ph_knn_last_path: which
  * one the last k-NN call of this process ran (0 popcount, 1 matrix cores). */
 ph_status ph_knn_set_path(int mode);
 int ph_knn_last_path(void);

@@ -83,6 +83,7 @@ SIGNATURES = {
                                                 C.c_void_p, C.c_int, C.c_float, C.c_void_p,
                                                 C.c_void_p, C.c_void_p]),
     "ph_set_profiling": (C.c_int, [C.c_int]),
+    "ph_knn_last_prepass_timing": (C.c_int, [C.POINTER(C.c_float)]),
     "ph_knn_set_path": (C.c_int, [C.c_int]),
     "ph_knn_last_path": (C.c_int, []),
     "ph_knn_last_timing": (C.c_int, [_f32p, _f32p]),

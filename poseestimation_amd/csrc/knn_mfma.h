@@ -37,8 +37,10 @@ bool knn_mfma_pays_frames(int n_frames, int64_t max_nq, int64_t max_nt);
 // Bytes of the FP4 image of `rows` descriptors (128 per row, padding included).
 size_t knn_mfma_expanded_bytes(int64_t rows);
 
-// 256-bit rows (32 bytes each, packed) -> FP4 image.
-hipError_t knn_mfma_expand_launch(const void *d_rows, int64_t rows, void *d_expanded,
+// 256-bit rows (32 bytes each, packed) -> FP4 images, two row sets in one launch
+// (either may be empty).
+hipError_t knn_mfma_expand_launch(const void *d_rows_a, int64_t rows_a, void *d_expanded_a,
+                                  const void *d_rows_b, int64_t rows_b, void *d_expanded_b,
                                   hipStream_t stream);
 
 MfmaPlan knn_mfma_plan(int64_t nq, int64_t nt, int n_cus);
@@ -48,7 +50,8 @@ MfmaPlan knn_mfma_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int6
 
 // Same contract as knn_launch: FP4 images of both sets (d_qx / d_tx, workspaces of
 // knn_mfma_expanded_bytes), the distance kernel, the merge of the splits.  events, when
-// given, bracket the distance kernel [0, 1] and the merge [1, 2]; [2, 3] is empty.
+// given (five of them), bracket the FP4 pre-pass [4, 0], the distance kernel [0, 1] and the
+// merge [1, 2]; [2, 3] is empty.
 hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, const void *d_train,
                            int64_t nt, int k, int32_t index_base, void *d_qx, void *d_tx,
                            uint32_t *d_part, int32_t *d_out_idx, int32_t *d_out_dist,

@@ -34,8 +34,12 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr float MF_NONE = -65536.0f;   // stays negative under 1024 additions of 32
+#ifdef POSEHIP_MF_NOSCALE // timing experiment only: results are wrong without the scale
+static constexpr int MF_SCALE_A = 0, MF_SCALE_B = 0;
+#else
 static constexpr int MF_SCALE_A = 0x89898989; // E8M0 2^10 in every byte
 static constexpr int MF_SCALE_B = 0x7F7F7F7F; // E8M0 2^0
+#endif
 
 // ---- bit -> FP4 expansion -------------------------------------------------------
 // 8 bits -> 8 nibbles: bit i moves to bit 4 i, then nibble = 0x6 (+4.0) | bit << 3 (sign).
@@ -49,13 +53,22 @@ __device__ __forceinline__ uint32_t fp4_from_bits8(uint32_t b)
 
 // One thread per 32 descriptor bits: dword c of row i -> 16 bytes at piece c of the
 // expanded row (128 bytes per row).  K order is the same for every row, which is all the
-// dot product needs.
-__global__ __launch_bounds__(256) void fp4_expand_kernel(const uint32_t *__restrict__ rows,
-                                                         int64_t n_dwords,
-                                                         uint4 *__restrict__ out)
+// dot product needs.  Two row sets (query and train) in one launch: blocks below
+// blocks_a take set a.
+__global__ __launch_bounds__(256) void fp4_expand_kernel(const uint32_t *__restrict__ rows_a,
+                                                         int64_t n_dwords_a,
+                                                         uint4 *__restrict__ out_a,
+                                                         unsigned blocks_a,
+                                                         const uint32_t *__restrict__ rows_b,
+                                                         int64_t n_dwords_b,
+                                                         uint4 *__restrict__ out_b)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_dwords)
+    const bool second = blockIdx.x >= blocks_a;
+    const uint32_t *__restrict__ rows = second ? rows_b : rows_a;
+    uint4 *__restrict__ out = second ? out_b : out_a;
+    const int64_t n = second ? n_dwords_b : n_dwords_a;
+    const int64_t i = (int64_t)(blockIdx.x - (second ? blocks_a : 0)) * 256 + threadIdx.x;
+    if (i >= n)
         return;
     const uint32_t w = rows[i];
     out[i] = make_uint4(fp4_from_bits8(w & 0xFF), fp4_from_bits8((w >> 8) & 0xFF),
@@ -248,7 +261,9 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ qx,
             a[s] = frag(lds[0][s * 64 + lane]);
         for (int t = 0; t + 1 < n_tiles; t++) {
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#ifndef POSEHIP_MF_NOBARRIER // timing experiment only: racy without it
             __builtin_amdgcn_s_barrier();
+#endif
             load_to_lds(src + (int64_t)(t + 4) * 256, &lds[t & 3][wave * 64]);
             mfma_tile<K, QT, false, true>(a, b, c0, m1, m2, pend0, pend1, 32, h,
                                           &lds[(t + 1) & 3][lane]);
@@ -308,6 +323,11 @@ __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_kernel(
 // A batch of independent matching problems (grid.z = frame), as knn_partial_frames_kernel:
 // frame f matches query rows [q_off[f], q_off[f+1]) against train rows [t_off[f],
 // t_off[f+1]).  qx / tx are the FP4 images of the rows from q_row0 / t_row0 on.
+#ifdef POSEHIP_MF_CLOCKS
+// measurement build (tools/mfma_probe): shader cycles and 100 MHz wall ticks one workgroup spent
+__device__ unsigned long long mf_clock_probe[2];
+#endif
+
 template <int K, int QT>
 __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_frames_kernel(
     const uint4 *__restrict__ qx, const uint4 *__restrict__ tx, const int32_t *__restrict__ q_off,
@@ -329,8 +349,17 @@ __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_frames_kernel(
     const int64_t t0 = t_off[f], nt = t_off[f + 1] - t0;
     if ((int64_t)bx * (MF_WAVES * QT * 32) >= nq)
         return;
+#ifdef POSEHIP_MF_CLOCKS
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+#endif
     knn_mfma_body<K, QT>(qx + 8 * (q0 - q_row0), tx + 8 * (t0 - t_row0), nq, nt,
                          mfma_rows_per_split(nt, (int)gridDim.y), part, q0, total_nq, bx, by);
+#ifdef POSEHIP_MF_CLOCKS
+    if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 3 && threadIdx.x == 0) {
+        mf_clock_probe[0] = __builtin_readcyclecounter() - c0;
+        mf_clock_probe[1] = wall_clock64() - w0;
+    }
+#endif
 }
 
 // ---- launchers ---------------------------------------------------------------------
@@ -340,14 +369,19 @@ size_t knn_mfma_expanded_bytes(int64_t rows)
     return (size_t)(rows + MF_PAD_ROWS) * 128;
 }
 
-hipError_t knn_mfma_expand_launch(const void *d_rows, int64_t rows, void *d_expanded,
+hipError_t knn_mfma_expand_launch(const void *d_rows_a, int64_t rows_a, void *d_expanded_a,
+                                  const void *d_rows_b, int64_t rows_b, void *d_expanded_b,
                                   hipStream_t stream)
 {
-    const int64_t n = rows * 8;
-    if (n <= 0)
+    const int64_t na = rows_a > 0 ? rows_a * 8 : 0, nb = rows_b > 0 ? rows_b * 8 : 0;
+    const int64_t ba = (na + 255) / 256, bb = (nb + 255) / 256;
+    if (ba + bb <= 0)
         return hipSuccess;
-    fp4_expand_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(
-        (const uint32_t *)d_rows, n, (uint4 *)d_expanded);
+    if (ba + bb > 0x7FFFFFFF)
+        return hipErrorInvalidValue;
+    fp4_expand_kernel<<<(unsigned)(ba + bb), 256, 0, stream>>>(
+        (const uint32_t *)d_rows_a, na, (uint4 *)d_expanded_a, (unsigned)ba,
+        (const uint32_t *)d_rows_b, nb, (uint4 *)d_expanded_b);
     return hipGetLastError();
 }
 
@@ -399,14 +433,18 @@ MfmaPlan knn_mfma_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int6
     return p;
 }
 
+// Measured on MI355X (tools/path_crossover.py, whole calls on resident inputs): the
+// pre-pass and the extra launches cost about 5 us, which the matrix cores win back from
+// about 3e7 pairs on (5000 x 5000; 2.1x at 10k x 10k, 5x at 200k x 60k); query sets too
+// short to fill the 128-query minimum of a workgroup stay with the popcount kernel.
 bool knn_mfma_pays(int64_t nq, int64_t nt)
 {
-    return nq >= 1024 && nt >= 1024 && nq * nt >= ((int64_t)1 << 23);
+    return nq >= 256 && nt >= 256 && nq * nt >= 30000000;
 }
 
 bool knn_mfma_pays_frames(int n_frames, int64_t max_nq, int64_t max_nt)
 {
-    return max_nq >= 128 && max_nt >= 256 && (int64_t)n_frames * max_nq * max_nt >= ((int64_t)1 << 23);
+    return max_nq >= 256 && max_nt >= 256 && (int64_t)n_frames * max_nq * max_nt >= 40000000;
 }
 
 static hipError_t record(hipEvent_t *events, int i, hipStream_t stream)
@@ -424,9 +462,9 @@ hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, c
         (uint64_t)p.q_blocks * (uint64_t)p.n_splits >= (1ull << 31))
         return hipErrorInvalidValue;
     hipError_t e;
-    if ((e = knn_mfma_expand_launch(d_query, nq, d_qx, stream)) != hipSuccess)
+    if ((e = record(events, 4, stream)) != hipSuccess)
         return e;
-    if ((e = knn_mfma_expand_launch(d_train, nt, d_tx, stream)) != hipSuccess)
+    if ((e = knn_mfma_expand_launch(d_query, nq, d_qx, d_train, nt, d_tx, stream)) != hipSuccess)
         return e;
     if ((e = record(events, 0, stream)) != hipSuccess)
         return e;
@@ -473,10 +511,10 @@ hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const 
                             (uint64_t)p.q_blocks * (uint64_t)p.n_splits * (uint64_t)n_frames < (1ull << 31)
                         ? 1 : 0;
     hipError_t e;
-    if ((e = knn_mfma_expand_launch((const uint8_t *)d_query + q_begin * 32, q_end - q_begin, d_qx,
-                                    stream)) != hipSuccess)
+    if ((e = record(events, 4, stream)) != hipSuccess)
         return e;
-    if ((e = knn_mfma_expand_launch((const uint8_t *)d_train + t_begin * 32, t_end - t_begin, d_tx,
+    if ((e = knn_mfma_expand_launch((const uint8_t *)d_query + q_begin * 32, q_end - q_begin, d_qx,
+                                    (const uint8_t *)d_train + t_begin * 32, t_end - t_begin, d_tx,
                                     stream)) != hipSuccess)
         return e;
     if ((e = record(events, 0, stream)) != hipSuccess)

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cfloat>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 #include <unordered_set>
@@ -149,7 +150,7 @@ struct Context {
     bool profiling = false;                 // record events around the distance kernel
     int knn_path = 0;                       // 0: by size, 1: popcount kernel only, 2: matrix cores only
     int last_path = 0;                      // distance kernel of the last k-NN call: 0 VALU, 1 MFMA
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // [4]: ahead of the FP4 pre-pass
     bool ev_valid = false;
 };
 
@@ -587,6 +588,12 @@ ph_status ph_init(int device)
     PH_HIP(hipStreamCreateWithFlags(&g_ctx.pnp_overlap.side, hipStreamNonBlocking));
     PH_HIP(hipEventCreateWithFlags(&g_ctx.pnp_overlap.solved, hipEventDisableTiming));
     PH_HIP(hipEventCreateWithFlags(&g_ctx.pnp_overlap.scored, hipEventDisableTiming));
+    if (const char *path = getenv("POSEHIP_KNN_PATH")) { // same values as ph_knn_set_path
+        if (!strcmp(path, "popcount") || !strcmp(path, "1"))
+            g_ctx.knn_path = 1;
+        else if (!strcmp(path, "matrix") || !strcmp(path, "2"))
+            g_ctx.knn_path = 2;
+    }
     g_ctx.device = device;
     g_ctx.ready = true;
     return PH_OK;
@@ -680,6 +687,22 @@ ph_status ph_knn_last_timing_overhead(float *empty_interval_ms)
         return fail(PH_ERR_INVALID_ARG, "no profiled k-NN call (ph_set_profiling(1) first)");
     PH_HIP(hipEventSynchronize(g_ctx.ev[3]));
     PH_HIP(hipEventElapsedTime(empty_interval_ms, g_ctx.ev[2], g_ctx.ev[3]));
+    return PH_OK;
+}
+
+ph_status ph_knn_last_prepass_timing(float *prepass_ms)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (!g_ctx.ev_valid || !prepass_ms)
+        return fail(PH_ERR_INVALID_ARG, "no profiled k-NN call (ph_set_profiling(1) first)");
+    *prepass_ms = 0.f;
+    if (g_ctx.last_path == 1) {
+        PH_HIP(hipEventSynchronize(g_ctx.ev[0]));
+        PH_HIP(hipEventElapsedTime(prepass_ms, g_ctx.ev[4], g_ctx.ev[0]));
+    }
     return PH_OK;
 }
 

@@ -1,8 +1,9 @@
 // Matrix-core k-NN probe: exactness against a CPU brute force on tie-heavy data, then
 // timing.  Build (from the repo root):
 //   hipcc --offload-arch=gfx950 -O3 -x hip tools/mfma_probe.cpp \
-//         poseestimation_amd/csrc/knn_mfma.hip -o tools/mfma_probe
-// Run: tools/mfma_probe [nq nt splits q_tiles reps]
+//         -mllvm -amdgpu-mfma-vgpr-form poseestimation_amd/csrc/knn_mfma.hip \
+//         poseestimation_amd/csrc/knn_hamming.hip -o tools/mfma_probe
+// Run: tools/mfma_probe [nq nt frames splits q_tiles [reps]]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -17,6 +18,12 @@
 #include "../poseestimation_amd/csrc/knn_mfma.h"
 
 using namespace posehip;
+
+#ifdef POSEHIP_MF_CLOCKS
+namespace posehip {
+extern __device__ unsigned long long mf_clock_probe[2];
+}
+#endif
 
 #define CK(x)                                                                                     \
     do {                                                                                          \
@@ -54,8 +61,6 @@ static std::vector<uint32_t> make_rows(int64_t n, int pool, int flips, uint32_t 
     return out;
 }
 
-static int g_ring = 1;
-
 static int check(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int k, int pool, int flips)
 {
     auto q = make_rows(nq, pool, flips, 1 + (uint32_t)nq), t = make_rows(nt, pool, flips, 7 + (uint32_t)nt);
@@ -65,64 +70,47 @@ static int check(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int k, int
     }
     void *dq, *dt, *dqx, *dtx;
     uint32_t *dpart;
+    int32_t *didx, *ddist;
     CK(hipMalloc(&dq, nq * 32));
     CK(hipMalloc(&dt, nt * 32));
     CK(hipMalloc(&dqx, knn_mfma_expanded_bytes(nq)));
     CK(hipMalloc(&dtx, knn_mfma_expanded_bytes(nt)));
+    CK(hipMalloc(&didx, nq * k * 4));
+    CK(hipMalloc(&ddist, nq * k * 4));
     CK(hipMemset(dqx, 0xFF, knn_mfma_expanded_bytes(nq)));
     CK(hipMemset(dtx, 0xFF, knn_mfma_expanded_bytes(nt)));
     CK(hipMemcpy(dq, q.data(), nq * 32, hipMemcpyHostToDevice));
     CK(hipMemcpy(dt, t.data(), nt * 32, hipMemcpyHostToDevice));
     MfmaPlan p = knn_mfma_plan_splits(nq, nt, q_tiles, splits);
-    p.ring = g_ring;
     CK(hipMalloc(&dpart, p.part_bytes));
-    CK(knn_mfma_expand_launch(dq, nq, dqx, 0));
-    CK(knn_mfma_expand_launch(dt, nt, dtx, 0));
-    CK(knn_mfma_partial_launch(p, dqx, nq, dtx, nt, k, dpart, 0));
+    CK(knn_mfma_launch(p, dq, nq, dt, nt, k, 0, dqx, dtx, dpart, didx, ddist, nullptr, 0.f, 0));
     CK(hipDeviceSynchronize());
-    std::vector<uint32_t> part(p.part_bytes / 4);
-    CK(hipMemcpy(part.data(), dpart, p.part_bytes, hipMemcpyDeviceToHost));
+    std::vector<int32_t> idx(nq * k), dist(nq * k);
+    CK(hipMemcpy(idx.data(), didx, nq * k * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(dist.data(), ddist, nq * k * 4, hipMemcpyDeviceToHost));
     int bad = 0;
     for (int64_t i = 0; i < nq; i++) {
-        // expected: two smallest (dist, idx)
-        uint64_t e1 = ~0ull, e2 = ~0ull;
+        uint64_t e[2] = {~0ull, ~0ull}; // expected: two smallest (dist, idx)
         for (int64_t j = 0; j < nt; j++) {
             const uint64_t key = ((uint64_t)ham(&q[i * 8], &t[j * 8]) << 32) | (uint64_t)j;
-            if (key < e1) {
-                e2 = e1;
-                e1 = key;
-            } else if (key < e2)
-                e2 = key;
+            if (key < e[0]) {
+                e[1] = e[0];
+                e[0] = key;
+            } else if (key < e[1])
+                e[1] = key;
         }
-        uint64_t g1 = ~0ull, g2 = ~0ull;
-        for (int s = 0; s < p.n_splits; s++)
-            for (int rnk = 0; rnk < 2; rnk++) {
-                const uint32_t kk = part[((size_t)s * 2 + rnk) * nq + i];
-                if (kk == 0xFFFFFFFFu)
-                    continue;
-                const uint64_t key = ((uint64_t)(kk >> KNN_KEY_SHIFT) << 32) |
-                                     (uint64_t)(s * p.rows_per_split + (kk & ((1u << KNN_KEY_SHIFT) - 1)));
-                if (key < g1) {
-                    g2 = g1;
-                    g1 = key;
-                } else if (key < g2)
-                    g2 = key;
+        for (int r = 0; r < k; r++) {
+            const int32_t wi = e[r] == ~0ull ? -1 : (int32_t)(e[r] & 0xFFFFFFFF);
+            const int32_t wd = e[r] == ~0ull ? 0x7FFFFFFF : (int32_t)(e[r] >> 32);
+            if (idx[i * k + r] != wi || dist[i * k + r] != wd) {
+                if (bad < 5)
+                    printf("  MISMATCH q=%lld rank %d: got (%d,%d) want (%d,%d)\n", (long long)i, r,
+                           dist[i * k + r], idx[i * k + r], wd, wi);
+                bad++;
             }
-        if (k == 1) {
-            e2 = ~0ull;
-            g2 = ~0ull;
-        }
-        if (g1 != e1 || g2 != e2) {
-            if (bad < 5)
-                printf("  MISMATCH q=%lld: got (%llu,%llu) (%llu,%llu) want (%llu,%llu) (%llu,%llu)\n",
-                       (long long)i, (unsigned long long)(g1 >> 32), (unsigned long long)(g1 & 0xFFFFFFFF),
-                       (unsigned long long)(g2 >> 32), (unsigned long long)(g2 & 0xFFFFFFFF),
-                       (unsigned long long)(e1 >> 32), (unsigned long long)(e1 & 0xFFFFFFFF),
-                       (unsigned long long)(e2 >> 32), (unsigned long long)(e2 & 0xFFFFFFFF));
-            bad++;
         }
     }
-    printf("ring=%d check nq=%lld nt=%lld splits=%d rows/split=%lld q_tiles=%d k=%d pool=%d flips=%d: %s (%d bad)\n",
+    printf("check nq=%lld nt=%lld splits=%d rows/split=%lld q_tiles=%d k=%d pool=%d flips=%d: %s (%d bad)\n",
            (long long)nq, (long long)nt, p.n_splits, (long long)p.rows_per_split, q_tiles, k, pool,
            flips, bad ? "FAIL" : "ok", bad);
     fflush(stdout);
@@ -131,90 +119,111 @@ static int check(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int k, int
     CK(hipFree(dqx));
     CK(hipFree(dtx));
     CK(hipFree(dpart));
+    CK(hipFree(didx));
+    CK(hipFree(ddist));
     return bad;
 }
 
-static void timeit(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int reps)
+// F frames of nq x nt in one launch (F == 1: the single-problem kernel)
+static void timeit(int64_t nq, int64_t nt, int F, int64_t splits, int q_tiles, int reps)
 {
-    auto q = make_rows(nq, 1 << 20, 0, 3), t = make_rows(nt, 1 << 20, 0, 5);
+    auto q = make_rows(nq * F, 1 << 20, 0, 3), t = make_rows(nt * F, 1 << 20, 0, 5);
     void *dq, *dt, *dqx, *dtx;
     uint32_t *dpart;
-    CK(hipMalloc(&dq, nq * 32));
-    CK(hipMalloc(&dt, nt * 32));
-    CK(hipMalloc(&dqx, knn_mfma_expanded_bytes(nq)));
-    CK(hipMalloc(&dtx, knn_mfma_expanded_bytes(nt)));
-    CK(hipMemcpy(dq, q.data(), nq * 32, hipMemcpyHostToDevice));
-    CK(hipMemcpy(dt, t.data(), nt * 32, hipMemcpyHostToDevice));
+    int32_t *didx, *ddist, *doff;
+    CK(hipMalloc(&dq, nq * F * 32));
+    CK(hipMalloc(&dt, nt * F * 32));
+    CK(hipMalloc(&dqx, knn_mfma_expanded_bytes(nq * F)));
+    CK(hipMalloc(&dtx, knn_mfma_expanded_bytes(nt * F)));
+    CK(hipMalloc(&didx, nq * F * 2 * 4));
+    CK(hipMalloc(&ddist, nq * F * 2 * 4));
+    CK(hipMemcpy(dq, q.data(), nq * F * 32, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dt, t.data(), nt * F * 32, hipMemcpyHostToDevice));
+    std::vector<int32_t> off(2 * (F + 1));
+    for (int f = 0; f <= F; f++) {
+        off[f] = (int32_t)(f * nq);
+        off[F + 1 + f] = (int32_t)(f * nt);
+    }
+    CK(hipMalloc(&doff, off.size() * 4));
+    CK(hipMemcpy(doff, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     MfmaPlan p = knn_mfma_plan_splits(nq, nt, q_tiles, splits);
-    p.ring = g_ring;
+    p.part_bytes *= F;
     CK(hipMalloc(&dpart, p.part_bytes));
-    hipEvent_t e0, e1, e2;
-    CK(hipEventCreate(&e0));
-    CK(hipEventCreate(&e1));
-    CK(hipEventCreate(&e2));
-    float best_x = 1e30f, best_k = 1e30f;
+    hipEvent_t ev[5];
+    for (auto &e : ev)
+        CK(hipEventCreate(&e));
+    float best[3] = {1e30f, 1e30f, 1e30f}, best_total = 1e30f;
     for (int r = 0; r < reps + 2; r++) {
-        CK(hipEventRecord(e0, 0));
-        CK(knn_mfma_expand_launch(dq, nq, dqx, 0));
-        CK(knn_mfma_expand_launch(dt, nt, dtx, 0));
-        CK(hipEventRecord(e1, 0));
-        CK(knn_mfma_partial_launch(p, dqx, nq, dtx, nt, 2, dpart, 0));
-        CK(hipEventRecord(e2, 0));
-        CK(hipEventSynchronize(e2));
-        float mx, mk;
-        CK(hipEventElapsedTime(&mx, e0, e1));
-        CK(hipEventElapsedTime(&mk, e1, e2));
+        if (F == 1)
+            CK(knn_mfma_launch(p, dq, nq, dt, nt, 2, 0, dqx, dtx, dpart, didx, ddist, nullptr, 0.f, 0, ev));
+        else
+            CK(knn_mfma_frames_launch(p, dq, doff, 0, nq * F, dt, doff + F + 1, 0, nt * F, F, 2, dqx,
+                                      dtx, dpart, didx, ddist, nullptr, 0.f, 0, ev, true));
+        CK(hipEventSynchronize(ev[3]));
+        float m[3], tot;
+        CK(hipEventElapsedTime(&m[0], ev[4], ev[0]));
+        CK(hipEventElapsedTime(&m[1], ev[0], ev[1]));
+        CK(hipEventElapsedTime(&m[2], ev[1], ev[2]));
+        CK(hipEventElapsedTime(&tot, ev[4], ev[2]));
         if (r >= 2) {
-            best_x = std::min(best_x, mx);
-            best_k = std::min(best_k, mk);
+            for (int i = 0; i < 3; i++)
+                best[i] = std::min(best[i], m[i]);
+            best_total = std::min(best_total, tot);
         }
     }
-    const double evals = (double)nq * (double)nt;
-    printf("ring=%d time nq=%lld nt=%lld splits=%d rows/split=%lld q_tiles=%d grid=%lldx%d: expand %.1f us, "
-           "kernel %.1f us = %.3e evals/s = %.2f PFLOP/s fp4\n",
-           g_ring, (long long)nq, (long long)nt, p.n_splits, (long long)p.rows_per_split, q_tiles,
-           (long long)p.q_blocks, p.n_splits, best_x * 1e3, best_k * 1e3, evals / (best_k * 1e-3),
-           evals * 512 / (best_k * 1e-3) / 1e15);
+    const double evals = (double)nq * (double)nt * F;
+    printf("time F=%d nq=%lld nt=%lld splits=%d rows/split=%lld q_tiles=%d grid=%lldx%dx%d: prepass %.1f us, "
+           "kernel %.1f us (%.3e evals/s, %.2f PFLOP/s fp4), merge %.1f us, all %.1f us (%.3e evals/s)\n",
+           F, (long long)nq, (long long)nt, p.n_splits, (long long)p.rows_per_split, q_tiles,
+           (long long)p.q_blocks, p.n_splits, F, best[0] * 1e3, best[1] * 1e3,
+           evals / (best[1] * 1e-3), evals * 512 / (best[1] * 1e-3) / 1e15, best[2] * 1e3,
+           best_total * 1e3, evals / (best_total * 1e-3));
+#ifdef POSEHIP_MF_CLOCKS
+    if (F > 3) {
+        unsigned long long c[2];
+        CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(posehip::mf_clock_probe), sizeof(c)));
+        const int tiles = (int)((p.rows_per_split + 31) / 32);
+        printf("  one workgroup: %llu shader cycles in %.2f us (%.0f MHz), %d tiles -> %.0f cycles per tile\n",
+               c[0], c[1] / 100.0, c[0] / (c[1] / 100.0), tiles, (double)c[0] / tiles);
+    }
+#endif
     fflush(stdout);
     CK(hipFree(dq));
     CK(hipFree(dt));
     CK(hipFree(dqx));
     CK(hipFree(dtx));
     CK(hipFree(dpart));
+    CK(hipFree(didx));
+    CK(hipFree(ddist));
+    CK(hipFree(doff));
 }
 
 int main(int argc, char **argv)
 {
-    if (argc >= 5) {
-        timeit(atoll(argv[1]), atoll(argv[2]), atoll(argv[3]), atoi(argv[4]),
-               argc > 5 ? atoi(argv[5]) : 5);
+    if (argc >= 6) { // nq nt F splits q_tiles [reps]
+        timeit(atoll(argv[1]), atoll(argv[2]), atoi(argv[3]), atoll(argv[4]), atoi(argv[5]),
+               argc > 6 ? atoi(argv[6]) : 5);
         return 0;
     }
     int bad = 0;
-    for (int ring : {1, 0}) {
-        g_ring = ring;
-        for (int qt : {4, 2, 8})
-            for (int k : {2, 1}) {
-                bad += check(700, 3001, 3, qt, k, 16, 3);
-                bad += check(33, 40, 1, qt, k, 4, 1);
-                bad += check(1, 1, 1, qt, k, 1, 0);
-                bad += check(513, 31, 1, qt, k, 1, 0);
-                bad += check(300, 2000, 1, qt, k, 1, 0); // all distances equal except row 3
-                bad += check(1500, 5000, 7, qt, k, 1 << 20, 0);
-                bad += check(200, 64, 1, qt, k, 2, 1);
-                bad += check(200, 65, 1, qt, k, 2, 1);
-                bad += check(200, 97, 2, qt, k, 2, 1);
-            }
-        bad += check(64, 40000, 1, 4, 2, 8, 2); // two splits of 32768 / 7232 rows: 1024 tiles
-    }
+    for (int qt : {4, 2})
+        for (int k : {2, 1}) {
+            bad += check(700, 3001, 3, qt, k, 16, 3);
+            bad += check(33, 40, 1, qt, k, 4, 1);
+            bad += check(1, 1, 1, qt, k, 1, 0);
+            bad += check(513, 31, 1, qt, k, 1, 0);
+            bad += check(300, 2000, 1, qt, k, 1, 0); // all distances equal except row 3
+            bad += check(1500, 5000, 7, qt, k, 1 << 20, 0);
+            bad += check(200, 64, 1, qt, k, 2, 1);
+            bad += check(200, 65, 1, qt, k, 2, 1);
+            bad += check(200, 97, 2, qt, k, 2, 1);
+        }
+    bad += check(64, 40000, 1, 4, 2, 8, 2); // two splits, the longer one close to 1024 tiles
     printf(bad ? "PROBE FAILED\n" : "PROBE OK\n");
     if (bad)
         return 1;
-    for (int ring : {1, 0}) {
-        g_ring = ring;
-        for (int qt : {4, 8, 2})
-            for (int splits : {1, 2, 4, 8})
-                timeit(163840, 10000, splits, qt, 5);
-    }
+    for (int qt : {4, 2})
+        for (int splits : {2, 3, 4, 5, 6, 8})
+            timeit(10000, 10000, 16, splits, qt, 5);
     return 0;
 }
