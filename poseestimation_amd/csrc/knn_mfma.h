@@ -8,9 +8,9 @@ namespace posehip {
 
 static constexpr int MF_WAVES = 4;                      // waves per workgroup
 static constexpr int64_t MF_MAX_ROWS_PER_SPLIT = 32768; // 1024 tiles: the key's index field
-// Rows an FP4 image is readable past its last row: a workgroup's query block (4 waves x
-// 4 tiles x 32 rows) and the train tiles loaded ahead may run over the end.
-static constexpr int64_t MF_PAD_ROWS = 1024;
+// Rows an FP4 image is readable past its last row: the train tiles loaded ahead (three
+// tiles of 32 rows) run over the end.
+static constexpr int64_t MF_PAD_ROWS = 256;
 
 struct MfmaPlan {
     int q_tiles;            // tiles of 32 queries per wave (2 or 4)
@@ -37,10 +37,8 @@ bool knn_mfma_pays_frames(int n_frames, int64_t max_nq, int64_t max_nt);
 // Bytes of the FP4 image of `rows` descriptors (128 per row, padding included).
 size_t knn_mfma_expanded_bytes(int64_t rows);
 
-// 256-bit rows (32 bytes each, packed) -> FP4 images, two row sets in one launch
-// (either may be empty).
-hipError_t knn_mfma_expand_launch(const void *d_rows_a, int64_t rows_a, void *d_expanded_a,
-                                  const void *d_rows_b, int64_t rows_b, void *d_expanded_b,
+// 256-bit rows (32 bytes each, packed) -> FP4 image.
+hipError_t knn_mfma_expand_launch(const void *d_rows, int64_t rows, void *d_expanded,
                                   hipStream_t stream);
 
 MfmaPlan knn_mfma_plan(int64_t nq, int64_t nt, int n_cus);
@@ -48,12 +46,12 @@ MfmaPlan knn_mfma_plan_splits(int64_t nq, int64_t nt, int q_tiles, int64_t split
 MfmaPlan knn_mfma_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int64_t total_nq,
                               int n_cus);
 
-// Same contract as knn_launch: FP4 images of both sets (d_qx / d_tx, workspaces of
-// knn_mfma_expanded_bytes), the distance kernel, the merge of the splits.  events, when
+// Same contract as knn_launch: FP4 image of the train set (d_tx, a workspace of
+// knn_mfma_expanded_bytes(nt)), the distance kernel, the merge of the splits.  events, when
 // given (five of them), bracket the FP4 pre-pass [4, 0], the distance kernel [0, 1] and the
 // merge [1, 2]; [2, 3] is empty.
 hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, const void *d_train,
-                           int64_t nt, int k, int32_t index_base, void *d_qx, void *d_tx,
+                           int64_t nt, int k, int32_t index_base, void *d_tx,
                            uint32_t *d_part, int32_t *d_out_idx, int32_t *d_out_dist,
                            uint8_t *d_keep, float ratio, hipStream_t stream,
                            hipEvent_t *events = nullptr);
@@ -63,7 +61,7 @@ hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, c
 hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const int32_t *d_q_off,
                                   int64_t q_begin, int64_t q_end, const void *d_train,
                                   const int32_t *d_t_off, int64_t t_begin, int64_t t_end,
-                                  int n_frames, int k, void *d_qx, void *d_tx, uint32_t *d_part,
+                                  int n_frames, int k, void *d_tx, uint32_t *d_part,
                                   int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,
                                   float ratio, hipStream_t stream, hipEvent_t *events = nullptr,
                                   bool uniform_frames = false);

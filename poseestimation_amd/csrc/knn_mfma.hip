@@ -19,8 +19,9 @@
 // v_max3 / v_med3 (1.25 ops per key).  The VALU therefore spends 22 instructions per
 // 16 keys where the popcount kernel spends 292.
 //
-// A workgroup is 4 waves; wave w holds QT tiles of 32 queries as B fragments in registers
-// for the whole kernel, all four waves stream the same train tiles, which an LDS-DMA ring
+// A workgroup is 4 waves; wave w expands its QT tiles of 32 queries to FP4 once and holds
+// them as B fragments in registers for the whole kernel; the train rows are expanded by a
+// pre-pass (128 bytes per row), all four waves stream the same train tiles, which an LDS-DMA ring
 // (global_load_lds, no VGPRs) stages in fragment order three tiles ahead.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -53,26 +54,20 @@ __device__ __forceinline__ uint32_t fp4_from_bits8(uint32_t b)
 
 // One thread per 32 descriptor bits: dword c of row i -> 16 bytes at piece c of the
 // expanded row (128 bytes per row).  K order is the same for every row, which is all the
-// dot product needs.  Two row sets (query and train) in one launch: blocks below
-// blocks_a take set a.
-__global__ __launch_bounds__(256) void fp4_expand_kernel(const uint32_t *__restrict__ rows_a,
-                                                         int64_t n_dwords_a,
-                                                         uint4 *__restrict__ out_a,
-                                                         unsigned blocks_a,
-                                                         const uint32_t *__restrict__ rows_b,
-                                                         int64_t n_dwords_b,
-                                                         uint4 *__restrict__ out_b)
+// dot product needs.
+__device__ __forceinline__ uint4 fp4_from_bits32(uint32_t w)
 {
-    const bool second = blockIdx.x >= blocks_a;
-    const uint32_t *__restrict__ rows = second ? rows_b : rows_a;
-    uint4 *__restrict__ out = second ? out_b : out_a;
-    const int64_t n = second ? n_dwords_b : n_dwords_a;
-    const int64_t i = (int64_t)(blockIdx.x - (second ? blocks_a : 0)) * 256 + threadIdx.x;
-    if (i >= n)
-        return;
-    const uint32_t w = rows[i];
-    out[i] = make_uint4(fp4_from_bits8(w & 0xFF), fp4_from_bits8((w >> 8) & 0xFF),
-                        fp4_from_bits8((w >> 16) & 0xFF), fp4_from_bits8(w >> 24));
+    return make_uint4(fp4_from_bits8(w & 0xFF), fp4_from_bits8((w >> 8) & 0xFF),
+                      fp4_from_bits8((w >> 16) & 0xFF), fp4_from_bits8(w >> 24));
+}
+
+__global__ __launch_bounds__(256) void fp4_expand_kernel(const uint32_t *__restrict__ rows,
+                                                         int64_t n_dwords,
+                                                         uint4 *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_dwords)
+        out[i] = fp4_from_bits32(rows[i]);
 }
 
 // ---- top-2 by maximum -------------------------------------------------------------
@@ -199,11 +194,12 @@ __device__ __forceinline__ void load_to_lds(const uint4 *g, uint4 *lds_wave_base
         (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// qx / tx: expanded rows of ONE matching problem (8 pieces of 16 bytes per row); both
-// buffers must be readable for MF_PAD_ROWS rows past their last row.  Output as in
+// q_raw: the nq >= 1 query rows of ONE matching problem as they are (32 bytes each); tx:
+// the FP4 image of its train rows (8 pieces of 16 bytes per row), readable for
+// MF_PAD_ROWS rows past the last one.  Output as in
 // knn_partial_body: part[split][rank][part_stride] keys local to the split.
 template <int K, int QT>
-__device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ qx,
+__device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ q_raw,
                                               const uint4 *__restrict__ tx, int64_t nq, int64_t nt,
                                               int64_t rows_per_split, uint32_t *__restrict__ part,
                                               int64_t part_row0, int64_t part_stride,
@@ -218,12 +214,19 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ qx,
     const int n_tiles = (n + 31) >> 5;
     const int64_t qbase = ((int64_t)q_block * MF_WAVES + wave) * (QT * 32);
 
+    // B fragments, expanded here from the raw rows (two uint4 per row): lane half h of
+    // k-step s holds piece 2 s + h, the FP4 image of dword 2 s + h of the row.  Rows past
+    // the problem's last are clamped (their results are never written).
     i32x8 b[QT][4];
 #pragma unroll
-    for (int j = 0; j < QT; j++)
+    for (int j = 0; j < QT; j++) {
+        const int64_t row = min(qbase + j * 32 + r, nq - 1);
+        const uint4 lo = q_raw[2 * row], hi = q_raw[2 * row + 1];
+        const uint32_t w[4] = {h ? lo.y : lo.x, h ? lo.w : lo.z, h ? hi.y : hi.x, h ? hi.w : hi.z};
 #pragma unroll
         for (int s = 0; s < 4; s++)
-            b[j][s] = frag(qx[(qbase + j * 32 + r) * 8 + 2 * s + h]);
+            b[j][s] = frag(fp4_from_bits32(w[s]));
+    }
 
     // accumulator register i of a lane in half h is train row (i & 3) + 8 (i >> 2) + 4 h
     f32x16 c0;
@@ -309,7 +312,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ qx,
 
 template <int K, int QT>
 __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_kernel(
-    const uint4 *__restrict__ qx, const uint4 *__restrict__ tx, int64_t nq, int64_t nt,
+    const uint4 *__restrict__ q_raw, const uint4 *__restrict__ tx, int64_t nq, int64_t nt,
     int64_t rows_per_split, uint32_t *__restrict__ part)
 {
     // XCD-contiguous order of the (split, query block) space, as in knn_partial_kernel
@@ -317,12 +320,13 @@ __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_kernel(
     const unsigned L = blockIdx.x + X * blockIdx.y;
     const unsigned base = N >> 3, rem = N & 7, c = L & 7;
     const unsigned nl = c * base + min(c, rem) + (L >> 3);
-    knn_mfma_body<K, QT>(qx, tx, nq, nt, rows_per_split, part, 0, nq, nl % X, nl / X);
+    knn_mfma_body<K, QT>(q_raw, tx, nq, nt, rows_per_split, part, 0, nq, nl % X, nl / X);
 }
 
 // A batch of independent matching problems (grid.z = frame), as knn_partial_frames_kernel:
 // frame f matches query rows [q_off[f], q_off[f+1]) against train rows [t_off[f],
-// t_off[f+1]).  qx / tx are the FP4 images of the rows from q_row0 / t_row0 on.
+// t_off[f+1]).  q_raw: the query buffer itself; tx: the FP4 image of the train rows from
+// t_row0 on.
 #ifdef POSEHIP_MF_CLOCKS
 // measurement build (tools/mfma_probe): shader cycles and 100 MHz wall ticks one workgroup spent
 __device__ unsigned long long mf_clock_probe[2];
@@ -330,8 +334,9 @@ __device__ unsigned long long mf_clock_probe[2];
 
 template <int K, int QT>
 __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_frames_kernel(
-    const uint4 *__restrict__ qx, const uint4 *__restrict__ tx, const int32_t *__restrict__ q_off,
-    const int32_t *__restrict__ t_off, int64_t q_row0, int64_t t_row0, int64_t total_nq,
+    const uint4 *__restrict__ q_raw, const uint4 *__restrict__ tx,
+    const int32_t *__restrict__ q_off, const int32_t *__restrict__ t_off, int64_t t_row0,
+    int64_t total_nq,
     uint32_t *__restrict__ part, int xcd_chunks)
 {
     unsigned bx = blockIdx.x, by = blockIdx.y, f = blockIdx.z;
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_frames_kernel(
 #ifdef POSEHIP_MF_CLOCKS
     const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
 #endif
-    knn_mfma_body<K, QT>(qx + 8 * (q0 - q_row0), tx + 8 * (t0 - t_row0), nq, nt,
+    knn_mfma_body<K, QT>(q_raw + 2 * q0, tx + 8 * (t0 - t_row0), nq, nt,
                          mfma_rows_per_split(nt, (int)gridDim.y), part, q0, total_nq, bx, by);
 #ifdef POSEHIP_MF_CLOCKS
     if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 3 && threadIdx.x == 0) {
@@ -369,19 +374,14 @@ size_t knn_mfma_expanded_bytes(int64_t rows)
     return (size_t)(rows + MF_PAD_ROWS) * 128;
 }
 
-hipError_t knn_mfma_expand_launch(const void *d_rows_a, int64_t rows_a, void *d_expanded_a,
-                                  const void *d_rows_b, int64_t rows_b, void *d_expanded_b,
+hipError_t knn_mfma_expand_launch(const void *d_rows, int64_t rows, void *d_expanded,
                                   hipStream_t stream)
 {
-    const int64_t na = rows_a > 0 ? rows_a * 8 : 0, nb = rows_b > 0 ? rows_b * 8 : 0;
-    const int64_t ba = (na + 255) / 256, bb = (nb + 255) / 256;
-    if (ba + bb <= 0)
+    const int64_t n = rows * 8;
+    if (n <= 0)
         return hipSuccess;
-    if (ba + bb > 0x7FFFFFFF)
-        return hipErrorInvalidValue;
-    fp4_expand_kernel<<<(unsigned)(ba + bb), 256, 0, stream>>>(
-        (const uint32_t *)d_rows_a, na, (uint4 *)d_expanded_a, (unsigned)ba,
-        (const uint32_t *)d_rows_b, nb, (uint4 *)d_expanded_b);
+    fp4_expand_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(
+        (const uint32_t *)d_rows, n, (uint4 *)d_expanded);
     return hipGetLastError();
 }
 
@@ -453,7 +453,7 @@ static hipError_t record(hipEvent_t *events, int i, hipStream_t stream)
 }
 
 hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, const void *d_train,
-                           int64_t nt, int k, int32_t index_base, void *d_qx, void *d_tx,
+                           int64_t nt, int k, int32_t index_base, void *d_tx,
                            uint32_t *d_part, int32_t *d_out_idx, int32_t *d_out_dist,
                            uint8_t *d_keep, float ratio, hipStream_t stream, hipEvent_t *events)
 {
@@ -464,12 +464,12 @@ hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, c
     hipError_t e;
     if ((e = record(events, 4, stream)) != hipSuccess)
         return e;
-    if ((e = knn_mfma_expand_launch(d_query, nq, d_qx, d_train, nt, d_tx, stream)) != hipSuccess)
+    if ((e = knn_mfma_expand_launch(d_train, nt, d_tx, stream)) != hipSuccess)
         return e;
     if ((e = record(events, 0, stream)) != hipSuccess)
         return e;
     dim3 grid((unsigned)p.q_blocks, (unsigned)p.n_splits);
-    const uint4 *q4 = (const uint4 *)d_qx, *t4 = (const uint4 *)d_tx;
+    const uint4 *q4 = (const uint4 *)d_query, *t4 = (const uint4 *)d_tx;
 #define POSEHIP_MF_LAUNCH(KK, QQ)                                                               \
     knn_mfma_kernel<KK, QQ><<<grid, MF_WAVES * 64, 0, stream>>>(q4, t4, nq, nt,                \
                                                                 p.rows_per_split, d_part)
@@ -499,7 +499,7 @@ hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, c
 hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const int32_t *d_q_off,
                                   int64_t q_begin, int64_t q_end, const void *d_train,
                                   const int32_t *d_t_off, int64_t t_begin, int64_t t_end,
-                                  int n_frames, int k, void *d_qx, void *d_tx, uint32_t *d_part,
+                                  int n_frames, int k, void *d_tx, uint32_t *d_part,
                                   int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,
                                   float ratio, hipStream_t stream, hipEvent_t *events,
                                   bool uniform_frames)
@@ -513,17 +513,16 @@ hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const 
     hipError_t e;
     if ((e = record(events, 4, stream)) != hipSuccess)
         return e;
-    if ((e = knn_mfma_expand_launch((const uint8_t *)d_query + q_begin * 32, q_end - q_begin, d_qx,
-                                    (const uint8_t *)d_train + t_begin * 32, t_end - t_begin, d_tx,
+    if ((e = knn_mfma_expand_launch((const uint8_t *)d_train + t_begin * 32, t_end - t_begin, d_tx,
                                     stream)) != hipSuccess)
         return e;
     if ((e = record(events, 0, stream)) != hipSuccess)
         return e;
     dim3 grid((unsigned)p.q_blocks, (unsigned)p.n_splits, (unsigned)n_frames);
-    const uint4 *q4 = (const uint4 *)d_qx, *t4 = (const uint4 *)d_tx;
+    const uint4 *q4 = (const uint4 *)d_query, *t4 = (const uint4 *)d_tx;
 #define POSEHIP_MF_LAUNCH(KK, QQ)                                                               \
     knn_mfma_frames_kernel<KK, QQ><<<grid, MF_WAVES * 64, 0, stream>>>(                         \
-        q4, t4, d_q_off, d_t_off, q_begin, t_begin, q_end, d_part, xcd)
+        q4, t4, d_q_off, d_t_off, t_begin, q_end, d_part, xcd)
     if (p.q_tiles == 4 && k == 2)
         POSEHIP_MF_LAUNCH(2, 4);
     else if (p.q_tiles == 4)

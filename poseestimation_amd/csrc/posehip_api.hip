@@ -124,7 +124,7 @@ struct Context {
     hipStream_t stream = nullptr;
     DevBuf part;   // per-split keys of the distance kernel
     DevBuf part2;  // same, for the swapped pass of the cross-check
-    DevBuf xq, xt; // FP4 images of the query / train rows (matrix-core path)
+    DevBuf xt;     // FP4 image of the train rows (matrix-core path)
     DevBuf best;   // cross-check per-query 64-bit keys
     DevBuf tmp_i;  // cross-check per-train nearest query index
     DevBuf tmp_d;  // cross-check per-train nearest query distance
@@ -243,9 +243,8 @@ ph_status knn_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t n
         if (gs != PH_OK)
             return gs;
         PH_HIP(part.reserve(mp.part_bytes));
-        PH_HIP(g_ctx.xq.reserve(knn_mfma_expanded_bytes(nq)));
         PH_HIP(g_ctx.xt.reserve(knn_mfma_expanded_bytes(nt)));
-        PH_HIP(knn_mfma_launch(mp, d_q, nq, d_t, nt, k, base, g_ctx.xq.p, g_ctx.xt.p,
+        PH_HIP(knn_mfma_launch(mp, d_q, nq, d_t, nt, k, base, g_ctx.xt.p,
                                (uint32_t *)part.p, d_idx, d_dist, d_keep, ratio, st, ev));
         g_ctx.ev_valid = ev != nullptr;
         g_ctx.last_path = 1;
@@ -612,7 +611,7 @@ void ph_shutdown(void)
     }
     g_dbs.clear();
     DevBuf *all[] = {&g_ctx.part,  &g_ctx.part2, &g_ctx.best,   &g_ctx.tmp_i,
-                     &g_ctx.tmp_d, &g_ctx.d_in,  &g_ctx.pnp_idx, &g_ctx.xq,   &g_ctx.xt};
+                     &g_ctx.tmp_d, &g_ctx.d_in,  &g_ctx.pnp_idx, &g_ctx.xt};
     for (DevBuf *b : all)
         b->release();
     g_ctx.h_in.release();
@@ -798,16 +797,15 @@ ph_status knn_frames_locked(const FrameSide &q, const FrameSide &t, int n_frames
         return s;
     PH_HIP(part.reserve(mfma ? mp.part_bytes : plan.part_bytes));
     if (mfma) {
-        PH_HIP(g_ctx.xq.reserve(knn_mfma_expanded_bytes(q.end - q.begin)));
         PH_HIP(g_ctx.xt.reserve(knn_mfma_expanded_bytes(t.end - t.begin)));
     }
     if ((s = upload_frame_tables(q.offsets, t.offsets, n_frames, st, fb, slot)) != PH_OK)
         return s;
     if (mfma)
         PH_HIP(knn_mfma_frames_launch(mp, q.d_rows, fb.d_q_off, q.begin, q.end, t.d_rows,
-                                      fb.d_t_off, t.begin, t.end, n_frames, k, g_ctx.xq.p,
-                                      g_ctx.xt.p, (uint32_t *)part.p, d_out_idx, d_out_dist,
-                                      d_keep, ratio, st, ev, uniform));
+                                      fb.d_t_off, t.begin, t.end, n_frames, k, g_ctx.xt.p,
+                                      (uint32_t *)part.p, d_out_idx, d_out_dist, d_keep, ratio,
+                                      st, ev, uniform));
     else
         PH_HIP(knn_frames_launch(plan, q.d_rows, fb.d_q_off, t.d_rows, fb.d_t_off, n_frames, q.end,
                                  k, (uint32_t *)part.p, d_out_idx, d_out_dist, d_keep, ratio, st,

@@ -83,7 +83,7 @@ static int check(int64_t nq, int64_t nt, int64_t splits, int q_tiles, int k, int
     CK(hipMemcpy(dt, t.data(), nt * 32, hipMemcpyHostToDevice));
     MfmaPlan p = knn_mfma_plan_splits(nq, nt, q_tiles, splits);
     CK(hipMalloc(&dpart, p.part_bytes));
-    CK(knn_mfma_launch(p, dq, nq, dt, nt, k, 0, dqx, dtx, dpart, didx, ddist, nullptr, 0.f, 0));
+    CK(knn_mfma_launch(p, dq, nq, dt, nt, k, 0, dtx, dpart, didx, ddist, nullptr, 0.f, 0));
     CK(hipDeviceSynchronize());
     std::vector<int32_t> idx(nq * k), dist(nq * k);
     CK(hipMemcpy(idx.data(), didx, nq * k * 4, hipMemcpyDeviceToHost));
@@ -155,9 +155,9 @@ static void timeit(int64_t nq, int64_t nt, int F, int64_t splits, int q_tiles, i
     float best[3] = {1e30f, 1e30f, 1e30f}, best_total = 1e30f;
     for (int r = 0; r < reps + 2; r++) {
         if (F == 1)
-            CK(knn_mfma_launch(p, dq, nq, dt, nt, 2, 0, dqx, dtx, dpart, didx, ddist, nullptr, 0.f, 0, ev));
+            CK(knn_mfma_launch(p, dq, nq, dt, nt, 2, 0, dtx, dpart, didx, ddist, nullptr, 0.f, 0, ev));
         else
-            CK(knn_mfma_frames_launch(p, dq, doff, 0, nq * F, dt, doff + F + 1, 0, nt * F, F, 2, dqx,
+            CK(knn_mfma_frames_launch(p, dq, doff, 0, nq * F, dt, doff + F + 1, 0, nt * F, F, 2,
                                       dtx, dpart, didx, ddist, nullptr, 0.f, 0, ev, true));
         CK(hipEventSynchronize(ev[3]));
         float m[3], tot;
