@@ -1,7 +1,9 @@
 """Randomised differential run of the matcher entry points against the CPU oracle
 (shapes around the block, group and split boundaries, ragged and uniform frame batches,
 tie-heavy data).  Not part of the test suite; run it after kernel changes:
-    python tools/fuzz_matcher.py [seconds] [seed]"""
+    python tools/fuzz_matcher.py [seconds] [seed]
+POSEHIP_KNN_PATH=matrix (or popcount) in the environment pins the distance kernel; by default
+the library picks by size, which at these shapes is mostly the popcount kernel."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -18,7 +20,7 @@ INT_MAX = 2147483647
 
 
 def size():
-    base = int(rng.choice([1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 500, 1000, 1023, 1024,
+    base = int(rng.choice([1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 500, 511, 512, 513, 1000, 1023, 1024,
                            1025, 2047, 2048, 4099, 8191, 8193]))
     return max(0, base + int(rng.integers(-2, 3))) if rng.random() < 0.5 else int(rng.integers(0, 6000))
 
