@@ -119,7 +119,11 @@ ph_status ph_ratio_filter(const int32_t *idx, const int32_t *dist, int nq, float
  * ph_db_device_ptr is the packed device buffer for the device entry points
  * below.  ph_db_knn_hamming256 is ph_knn_hamming256 against the resident set
  * (host queries, host results; keep may be NULL, otherwise k must be 2 and
- * keep[i] receives the ratio test's verdict). */
+ * keep[i] receives the ratio test's verdict); ph_db_knn_hamming256_dev is
+ * ph_knn_hamming256_dev against it (device queries and results, only enqueues).
+ * Both keep whatever the distance kernel needs beside the rows (the FP4 image of
+ * the matrix-core path, 128 bytes per row, built by the first large call) with
+ * the handle, so a call pays for the queries only. */
 typedef struct ph_db ph_db;
 ph_status ph_db_upload(const uint8_t *train, int64_t nt, size_t t_step, ph_db **db);
 ph_status ph_db_free(ph_db *db);
@@ -128,6 +132,9 @@ const void *ph_db_device_ptr(const ph_db *db); /* NULL for a dead handle or an e
 ph_status ph_db_knn_hamming256(const ph_db *db, const uint8_t *query, int64_t nq, size_t q_step,
                                int k, int32_t *out_idx, int32_t *out_dist, uint8_t *keep,
                                float ratio);
+ph_status ph_db_knn_hamming256_dev(const ph_db *db, const void *d_query, int64_t nq, int k,
+                                   int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,
+                                   float ratio, void *stream);
 
 /* ---- descriptor matching, device buffers --------------------------------- */
 

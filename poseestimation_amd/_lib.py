@@ -54,6 +54,8 @@ SIGNATURES = {
     "ph_db_device_ptr": (C.c_void_p, [C.c_void_p]),
     "ph_db_knn_hamming256": (C.c_int, [C.c_void_p, _u8p, C.c_int64, C.c_size_t, C.c_int, _i32p,
                                        _i32p, _u8p, C.c_float]),
+    "ph_db_knn_hamming256_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "ph_knn_hamming256_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                         C.c_void_p]),

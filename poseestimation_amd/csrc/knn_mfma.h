@@ -47,7 +47,8 @@ MfmaPlan knn_mfma_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int6
                               int n_cus);
 
 // Same contract as knn_launch: FP4 image of the train set (d_tx, a workspace of
-// knn_mfma_expanded_bytes(nt)), the distance kernel, the merge of the splits.  events, when
+// knn_mfma_expanded_bytes(nt)), the distance kernel, the merge of the splits.  d_train ==
+// nullptr: d_tx already holds the image (a resident train set), no pre-pass.  events, when
 // given (five of them), bracket the FP4 pre-pass [4, 0], the distance kernel [0, 1] and the
 // merge [1, 2]; [2, 3] is empty.
 hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, const void *d_train,

@@ -464,7 +464,7 @@ hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, c
     hipError_t e;
     if ((e = record(events, 4, stream)) != hipSuccess)
         return e;
-    if ((e = knn_mfma_expand_launch(d_train, nt, d_tx, stream)) != hipSuccess)
+    if (d_train && (e = knn_mfma_expand_launch(d_train, nt, d_tx, stream)) != hipSuccess)
         return e;
     if ((e = record(events, 0, stream)) != hipSuccess)
         return e;

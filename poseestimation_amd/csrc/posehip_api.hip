@@ -22,6 +22,7 @@
 // A train set resident in HBM (ph_db_upload); opaque to the C ABI.
 struct ph_db {
     void *d = nullptr;
+    void *x = nullptr; // FP4 image of the rows, built by the first call that takes the matrix cores
     int64_t rows = 0;
     int device = -1;
 };
@@ -220,9 +221,10 @@ __global__ void fill_empty_kernel(int32_t *idx, int32_t *dist, uint8_t *keep, in
 }
 
 // k-NN on device buffers; the caller holds g_mu and has called ensure_ready().
+// db: the resident set d_t belongs to, if any (its FP4 image is built once and kept).
 ph_status knn_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t nt, int k,
                          int32_t base, int32_t *d_idx, int32_t *d_dist, uint8_t *d_keep,
-                         float ratio, DevBuf &part, hipStream_t st)
+                         float ratio, DevBuf &part, hipStream_t st, ph_db *db = nullptr)
 {
     if (nq == 0)
         return PH_OK;
@@ -243,8 +245,28 @@ ph_status knn_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t n
         if (gs != PH_OK)
             return gs;
         PH_HIP(part.reserve(mp.part_bytes));
-        PH_HIP(g_ctx.xt.reserve(knn_mfma_expanded_bytes(nt)));
-        PH_HIP(knn_mfma_launch(mp, d_q, nq, d_t, nt, k, base, g_ctx.xt.p,
+        void *image = nullptr;
+        const void *rows_to_expand = d_t;
+        if (db) {
+            if (!db->x) { // once per resident set; later calls on any stream find it complete
+                PH_HIP(hipMalloc(&db->x, knn_mfma_expanded_bytes(nt)));
+                hipError_t e = knn_mfma_expand_launch(d_t, nt, db->x, st);
+                if (e == hipSuccess)
+                    e = hipStreamSynchronize(st);
+                if (e != hipSuccess) {
+                    (void)hipFree(db->x);
+                    db->x = nullptr;
+                    return fail(PH_ERR_HIP, "building the FP4 image of the train set: %s",
+                                hipGetErrorString(e));
+                }
+            }
+            image = db->x;
+            rows_to_expand = nullptr;
+        } else {
+            PH_HIP(g_ctx.xt.reserve(knn_mfma_expanded_bytes(nt)));
+            image = g_ctx.xt.p;
+        }
+        PH_HIP(knn_mfma_launch(mp, d_q, nq, rows_to_expand, nt, k, base, image,
                                (uint32_t *)part.p, d_idx, d_dist, d_keep, ratio, st, ev));
         g_ctx.ev_valid = ev != nullptr;
         g_ctx.last_path = 1;
@@ -607,6 +629,7 @@ void ph_shutdown(void)
     (void)hipDeviceSynchronize(); // callers' streams may still hold work that uses the workspace
     for (ph_db *db : g_dbs) {
         (void)hipFree(db->d);
+        (void)hipFree(db->x);
         delete db;
     }
     g_dbs.clear();
@@ -1118,6 +1141,7 @@ ph_status ph_db_free(ph_db *db)
         return s;
     (void)hipDeviceSynchronize(); // queued work may still read it
     (void)hipFree(db->d);
+    (void)hipFree(db->x);
     g_dbs.erase(db);
     delete db;
     return PH_OK;
@@ -1167,7 +1191,7 @@ ph_status ph_db_knn_hamming256(const ph_db *db, const uint8_t *query, int64_t nq
     uint8_t *hb = (uint8_t *)g_ctx.h_out.p, *dbuf = (uint8_t *)g_ctx.h_out.dp;
     if ((s = knn_dev_locked(d_q, nq, db->d, db->rows, k, 0, (int32_t *)dbuf,
                             (int32_t *)(dbuf + dist_off), keep ? dbuf + keep_off : nullptr, ratio,
-                            g_ctx.part, st)) != PH_OK)
+                            g_ctx.part, st, const_cast<ph_db *>(db))) != PH_OK)
         return s;
     PH_HIP(hipStreamSynchronize(st));
     memcpy(out_idx, hb, n_out * sizeof(int32_t));
@@ -1175,6 +1199,28 @@ ph_status ph_db_knn_hamming256(const ph_db *db, const uint8_t *query, int64_t nq
     if (keep)
         memcpy(keep, hb + keep_off, (size_t)nq);
     return PH_OK;
+}
+
+ph_status ph_db_knn_hamming256_dev(const ph_db *db, const void *d_query, int64_t nq, int k,
+                                   int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,
+                                   float ratio, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (!db || !g_dbs.count(const_cast<ph_db *>(db)))
+        return fail(PH_ERR_INVALID_ARG, "not a live train-set handle");
+    if (k != 1 && k != 2)
+        return fail(PH_ERR_INVALID_ARG, "k must be 1 or 2 (got %d)", k);
+    if (d_keep && k != 2)
+        return fail(PH_ERR_INVALID_ARG, "the ratio test needs k == 2");
+    if ((s = check_rows(d_query, nq, "query")) != PH_OK)
+        return s;
+    if (nq > 0 && (!d_out_idx || !d_out_dist))
+        return fail(PH_ERR_INVALID_ARG, "null output pointer");
+    return knn_dev_locked(d_query, nq, db->d, db->rows, k, 0, d_out_idx, d_out_dist, d_keep, ratio,
+                          g_ctx.part, pick_stream(stream), const_cast<ph_db *>(db));
 }
 
 ph_status ph_ransac_subsets(uint64_t rng_state, int n_points, int n_subsets, int32_t *out)

@@ -652,3 +652,45 @@ def test_resident_train_collection(posehip):
         orc.ratio_filter(ridx, rdist, 0.8)
     posehip.check(lib.ph_db_free(h))
     assert lib.ph_db_rows(h) == -1 and lib.ph_db_free(h) == 1    # dead handle: refused, no crash
+
+
+@all_paths
+def test_resident_database_device_queries(posehip):
+    """A 50k-row database uploaded once, frames of 2000 device-resident queries matched
+    against it (BASELINE configs[3] in small): every call equals ph_knn_hamming256_dev on
+    the same buffers and the oracle on sampled rows; the second and third call reuse what
+    the first one built for the handle; an empty database and a dead handle are handled."""
+    import torch
+    lib = posehip.load()
+    u8 = C.POINTER(C.c_uint8)
+    t = datagen.random_descriptors(50_000, 31)
+    h = C.c_void_p()
+    posehip.check(lib.ph_db_upload(t.ctypes.data_as(u8), t.shape[0], 32, C.byref(h)))
+    d_t = _dev(t)
+    for call, nq in enumerate([2000, 2000, 1]):
+        q = datagen.random_descriptors(nq, 40 + call)
+        q[0] = t[49_999 - call]  # an exact hit near the end of the database
+        d_q = _dev(q)
+        idx = torch.empty((nq, 2), dtype=torch.int32, device=d_q.device)
+        dist = torch.empty_like(idx)
+        keep = torch.empty((nq,), dtype=torch.uint8, device=d_q.device)
+        posehip.check(lib.ph_db_knn_hamming256_dev(h, d_q.data_ptr(), nq, 2, idx.data_ptr(),
+                                                   dist.data_ptr(), keep.data_ptr(),
+                                                   C.c_float(0.75), None))
+        posehip.check(lib.ph_stream_synchronize(None))
+        ridx, rdist, rkeep = gpu_knn_dev(posehip, d_q, d_t, 2, ratio=0.75)
+        assert torch.equal(idx, ridx) and torch.equal(dist, rdist) and torch.equal(keep, rkeep)
+        rows = np.arange(min(nq, 64))
+        oi, od = orc.knn(q[rows], t, 2, threads=8)
+        assert np.array_equal(idx.cpu().numpy()[rows], oi) and np.array_equal(dist.cpu().numpy()[rows], od)
+        assert idx[0, 0].item() == 49_999 - call and dist[0, 0].item() == 0
+    posehip.check(lib.ph_db_free(h))
+    assert lib.ph_db_knn_hamming256_dev(h, d_q.data_ptr(), 1, 2, idx.data_ptr(), dist.data_ptr(), None,
+                                        C.c_float(0), None) != 0
+    empty = C.c_void_p()
+    posehip.check(lib.ph_db_upload(None, 0, 32, C.byref(empty)))
+    posehip.check(lib.ph_db_knn_hamming256_dev(empty, d_q.data_ptr(), 1, 2, idx.data_ptr(),
+                                               dist.data_ptr(), None, C.c_float(0), None))
+    posehip.check(lib.ph_stream_synchronize(None))
+    assert idx[0].tolist() == [-1, -1] and dist[0].tolist() == [INT_MAX, INT_MAX]
+    posehip.check(lib.ph_db_free(empty))

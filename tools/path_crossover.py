@@ -78,3 +78,25 @@ single(10000, 10000, k=1)
 for F, nq, nt in ((64, 500, 500), (256, 500, 500), (16, 1000, 1000), (16, 2000, 2000), (64, 2000, 2000),
                   (8, 4000, 4000), (16, 10000, 10000), (4, 10000, 10000), (64, 128, 4000), (64, 4000, 128)):
     frames(F, nq, nt)
+
+
+def resident(nq, nt, k=2):
+    """A resident train set (its FP4 image is kept with the handle) against the plain call."""
+    q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev)
+    t_host = np.random.default_rng(1).integers(0, 256, size=(nt, 32), dtype=np.uint8)
+    t = torch.from_numpy(t_host).to(dev)
+    idx = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    h = C.c_void_p()
+    _lib.check(lib.ph_db_upload(t_host.ctypes.data_as(C.POINTER(C.c_uint8)), nt, 32, C.byref(h)))
+    plain = time_call(lambda: _lib.check(lib.ph_knn_hamming256_dev(
+        q.data_ptr(), nq, t.data_ptr(), nt, k, 0, idx.data_ptr(), dist.data_ptr(), None, C.c_float(0), sptr)))
+    res = time_call(lambda: _lib.check(lib.ph_db_knn_hamming256_dev(
+        h, q.data_ptr(), nq, k, idx.data_ptr(), dist.data_ptr(), None, C.c_float(0), sptr)))
+    _lib.check(lib.ph_db_free(h))
+    print(f"resident {nq:>7} x {nt:>8}: plain call {plain:8.1f} us, resident set {res:8.1f} us "
+          f"({plain / res:.2f}x)", flush=True)
+
+
+for nq, nt in ((2000, 50000), (10000, 10000), (2000, 1000000), (100000, 50000)):
+    resident(nq, nt)
