@@ -7,7 +7,8 @@ Workload at every N (weak scaling): per rank, a step is one pass over a batch of
 query and train descriptors, inputs resident in HBM; the batch goes down as one
 `ph_knn_hamming256_frames_dev` launch.  Frames are independent, so ranks share
 nothing and no collective is on the data path.  The same frames issued as one
-`ph_knn_hamming256_dev` call each are timed beside it (`per_call`).
+`ph_knn_hamming256_dev` call each are timed beside it (`per_call`), and so is the same
+step on the popcount kernel (`popcount_kernel`) when the matrix cores ran it.
 
 Prints one JSON line on rank 0.
 """
@@ -32,7 +33,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--nt", type=int, default=10000)
-    ap.add_argument("--frames-per-step", type=int, default=16)
+    ap.add_argument("--frames-per-step", type=int, default=64)
     ap.add_argument("--ratio", type=float, default=0.75)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
@@ -297,6 +298,7 @@ def main():
                     pp.append(a.value)
             _lib.check(lib.ph_set_profiling(0))
             prepass_ms = float(np.mean(pp)) - event_ms
+        torch.cuda.synchronize()  # the peak kernel runs on the library's stream: nothing beside it
         peak_ops = C.c_double(0)
         _lib.check(lib.ph_valu_popcount_peak(4000, C.byref(peak_ops)))
         peak_evals = peak_ops.value / 16.0
@@ -304,9 +306,12 @@ def main():
         kernel_name = "knn_mfma_frames_kernel" if mfma_path else "knn_partial_frames_kernel"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and (nq, nt, F) == (10000, 10000, 16):
+        if os.path.exists(tpath) and (nq, nt) == (10000, 10000):
             try:
-                traffic = json.load(open(tpath)).get(kernel_name + "_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get(kernel_name + "_bytes_per_launch_by_frames", {}).get(str(F))
+                if traffic is None and F == 16:
+                    traffic = tj.get(kernel_name + "_bytes_per_launch")
             except Exception:
                 traffic = None
 

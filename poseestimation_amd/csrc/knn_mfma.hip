@@ -214,6 +214,18 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ q_raw,
     const int n_tiles = (n + 31) >> 5;
     const int64_t qbase = ((int64_t)q_block * MF_WAVES + wave) * (QT * 32);
 
+    // LDS-DMA ring of four slots: thread (wave w, lane l) stages piece 2 w + (l >> 5) of tile
+    // row l & 31 into slot [w][l], so that k-step s of a tile is the 64 consecutive slots
+    // [s][0..63].  Every wave issues ONE load per tile, for tiles 0 .. n_tiles + 2 (the reads
+    // past the split stay inside the buffer's padding), so the count of loads in flight is the
+    // same at every wait.  The first four go out before anything else, under the query loads.
+    const uint4 *__restrict__ src = tx + (t0 + r) * 8 + 2 * wave + h;
+    if (n_tiles > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            load_to_lds(src + (int64_t)t * 256, &lds[t][wave * 64]);
+    }
+
     // B fragments, expanded here from the raw rows (two uint4 per row): lane half h of
     // k-step s holds piece 2 s + h, the FP4 image of dword 2 s + h of the row.  Rows past
     // the problem's last are clamped (their results are never written).
@@ -243,25 +255,18 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ q_raw,
     for (int i = 0; i < 16; i++)
         pend0[i] = pend1[i] = MF_NONE;
 
-    // thread (wave w, lane l) stages piece 2 w + (l >> 5) of tile row l & 31 into slot
-    // [w][l]: k-step s of the tile is then the 64 consecutive slots [s][0..63].
-    const uint4 *__restrict__ src = tx + (t0 + r) * 8 + 2 * wave + h;
     if (n_tiles > 0) {
-        // LDS-DMA ring of four slots.  Every wave issues ONE load per tile, for tiles
-        // 0 .. n_tiles + 2 (the reads past the split stay inside the buffer's padding), so
-        // the count of loads in flight is the same at every wait.  Iteration t: wait for
-        // the wave's own piece of tile t + 1 (two younger loads stay in flight), barrier --
-        // tile t + 1 is now complete and every wave has taken its fragments of tile t,
-        // whose slot the load of tile t + 4 may overwrite.
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-            load_to_lds(src + (int64_t)t * 256, &lds[t][wave * 64]);
+        // (tiles 0..3 were requested before the queries; the query loads behind them have
+        // returned, so have they)
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         i32x8 a[4];
 #pragma unroll
         for (int s = 0; s < 4; s++)
             a[s] = frag(lds[0][s * 64 + lane]);
+        // Iteration t: wait for the wave's own piece of tile t + 1 (two younger loads stay in
+        // flight), barrier -- tile t + 1 is now complete and every wave has taken its
+        // fragments of tile t, whose slot the load of tile t + 4 may overwrite.
         for (int t = 0; t + 1 < n_tiles; t++) {
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #ifndef POSEHIP_MF_NOBARRIER // timing experiment only: racy without it
