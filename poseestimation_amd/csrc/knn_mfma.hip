@@ -9,15 +9,16 @@
 // exactly (256 products of +-16 summed in fp32).  v_mfma_scale_f32_32x32x64_f8f6f4 forms a
 // 32 (train rows) x 32 (queries) tile of such dot products over 64 bits per instruction,
 // four instructions per tile; the block scale 2^10 and the accumulator input
-//     C[row] = 2^22 + 31 - row_in_tile
+//     C[row] = 2^22 + 31 - row_in_tile     (+ 32 in even tiles, see below)
 // turn the accumulator itself into an ordering key,
 //     key = (256 - hamming) * 2^15 + (31 - row_in_tile)            (an integer < 2^24),
 // whose MAXIMUM over a tile is the nearest train row, lowest row first among equals.  The
-// running best / second best of a lane carry an index field relative to the tile being
-// processed: 32 is added to both before every tile (two VALU ops), which keeps earlier
-// tiles ahead of later ones, and the sixteen keys of the tile are folded in with
-// v_max3 / v_med3 (1.25 ops per key).  The VALU therefore spends 22 instructions per
-// 16 keys where the popcount kernel spends 292.
+// running best / second best of a lane carry an index field relative to the PAIR of tiles
+// being processed (even tiles use C + 32, so a pair spans 64 index steps): 64 is added to
+// both before every pair (two VALU ops), which keeps earlier tiles ahead of later ones,
+// and the sixteen keys of a tile are folded in with v_max3 / v_med3 (1.25 ops per key).
+// The VALU therefore spends 21 instructions per 16 keys where the popcount kernel spends
+// 292.
 //
 // A workgroup is 4 waves; wave w expands its QT tiles of 32 queries to FP4 once and holds
 // them as B fragments in registers for the whole kernel; the train rows are expanded by a
@@ -25,6 +26,8 @@
 // (global_load_lds, no VGPRs) stages in fragment order three tiles ahead.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "knn_hamming.h"
 #include "knn_mfma.h"
@@ -111,7 +114,10 @@ __device__ __forceinline__ f32x16 mfma_chain(const i32x8 (&a)[4], const i32x8 (&
     return acc;
 }
 
-template <int K, bool MASKED>
+// Folds the 16 keys of one (train tile, query tile) into the lane's running pair.  AGE: the
+// keys belong to an even train tile, the first of its pair: the running keys first move one
+// pair of tiles (64 index steps) back.
+template <int K, bool MASKED, bool AGE>
 __device__ __forceinline__ void fold_tile(f32x16 acc, float &m1, float &m2, int valid, int h)
 {
     if constexpr (MASKED) {
@@ -120,9 +126,11 @@ __device__ __forceinline__ void fold_tile(f32x16 acc, float &m1, float &m2, int 
             if ((i & 3) + 8 * (i >> 2) + 4 * h >= valid)
                 acc[i] = MF_NONE;
     }
-    m1 += 32.0f;
-    if constexpr (K == 2)
-        m2 += 32.0f;
+    if constexpr (AGE) {
+        m1 += 64.0f;
+        if constexpr (K == 2)
+            m2 += 64.0f;
+    }
 #pragma unroll
     for (int g = 0; g < 4; g++)
         top2_max4<K>(m1, m2, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
@@ -138,21 +146,36 @@ __device__ __forceinline__ void fold_tile(f32x16 acc, float &m1, float &m2, int 
 // RELOAD: once every MFMA is issued, fetch the next tile's fragments.  The scheduler is
 // told to keep one MFMA per five or six VALU instructions, which is what the MFMA pipe
 // (32 cycles each) can hide.
-template <int K, int QT, bool LAST, bool RELOAD>
+// Scheduling pattern of one chain of four MFMAs with the fold that runs beside it (AGE:
+// that fold has two more VALU instructions).
+template <int K, bool AGE> __device__ __forceinline__ void sched_chain()
+{
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? (AGE ? 6 : 5) : (AGE ? 3 : 2), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? (AGE ? 6 : 5) : 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 5 : 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 5 : 2, 0);
+}
+
+template <int K, int QT, bool LAST, bool RELOAD, int PARITY>
 __device__ __forceinline__ void mfma_tile(i32x8 (&a)[4], const i32x8 (&b)[QT][4],
-                                          const f32x16 &c0, float (&m1)[QT], float (&m2)[QT],
+                                          const f32x16 &c, float (&m1)[QT], float (&m2)[QT],
                                           f32x16 &pend0, f32x16 &pend1, int valid, int h,
                                           const uint4 *next_frags)
 {
     static_assert(QT >= 2, "the fold lags two query tiles behind");
 #pragma unroll
     for (int j = 0; j < QT; j++) {
-        const f32x16 acc = mfma_chain(a, b[j], c0);
+        const f32x16 acc = mfma_chain(a, b[j], c);
         const int jf = (j + QT - 2) % QT; // the query tile pend0 belongs to
-        if (LAST && j >= 2)
-            fold_tile<K, true>(pend0, m1[jf], m2[jf], valid, h);
+        // j < 2: keys of the previous train tile (other parity, complete); else this tile's
+        if (j < 2)
+            fold_tile<K, false, PARITY == 1>(pend0, m1[jf], m2[jf], valid, h);
         else
-            fold_tile<K, false>(pend0, m1[jf], m2[jf], valid, h);
+            fold_tile<K, LAST, PARITY == 0>(pend0, m1[jf], m2[jf], valid, h);
         pend0 = pend1;
         pend1 = acc;
     }
@@ -162,27 +185,21 @@ __device__ __forceinline__ void mfma_tile(i32x8 (&a)[4], const i32x8 (&b)[QT][4]
             a[s] = frag(next_frags[s * 64]);
     }
     if constexpr (!LAST) {
+        sched_chain<K, PARITY == 1>();
+        sched_chain<K, PARITY == 1>();
 #pragma unroll
-        for (int j = 0; j < QT; j++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 6 : 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 6 : 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 5 : 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 5 : 2, 0);
-        }
+        for (int j = 2; j < QT; j++)
+            sched_chain<K, PARITY == 0>();
     }
 }
 
 // The folds still pending after a split's last tile (both belong to that tile).
-template <int K, int QT>
+template <int K, int QT, int PARITY>
 __device__ __forceinline__ void fold_pending(float (&m1)[QT], float (&m2)[QT], const f32x16 &pend0,
                                              const f32x16 &pend1, int valid, int h)
 {
-    fold_tile<K, true>(pend0, m1[QT - 2], m2[QT - 2], valid, h);
-    fold_tile<K, true>(pend1, m1[QT - 1], m2[QT - 1], valid, h);
+    fold_tile<K, true, PARITY == 0>(pend0, m1[QT - 2], m2[QT - 2], valid, h);
+    fold_tile<K, true, PARITY == 0>(pend1, m1[QT - 1], m2[QT - 1], valid, h);
 }
 
 // 16 bytes per lane from global memory straight into LDS (no VGPR in between): the wave's
@@ -241,10 +258,13 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ q_raw,
     }
 
     // accumulator register i of a lane in half h is train row (i & 3) + 8 (i >> 2) + 4 h
-    f32x16 c0;
+    // (even tiles carry 32 more in the index field than the odd tile of their pair)
+    f32x16 c0, c1;
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-        c0[i] = 4194304.0f + 31.0f - (float)((i & 3) + 8 * (i >> 2) + 4 * h);
+    for (int i = 0; i < 16; i++) {
+        c1[i] = 4194304.0f + 31.0f - (float)((i & 3) + 8 * (i >> 2) + 4 * h);
+        c0[i] = c1[i] + 32.0f;
+    }
 
     float m1[QT], m2[QT];
 #pragma unroll
@@ -267,19 +287,32 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ q_raw,
         // Iteration t: wait for the wave's own piece of tile t + 1 (two younger loads stay in
         // flight), barrier -- tile t + 1 is now complete and every wave has taken its
         // fragments of tile t, whose slot the load of tile t + 4 may overwrite.
-        for (int t = 0; t + 1 < n_tiles; t++) {
+        auto step = [&](int t, auto parity) {
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #ifndef POSEHIP_MF_NOBARRIER // timing experiment only: racy without it
             __builtin_amdgcn_s_barrier();
 #endif
             load_to_lds(src + (int64_t)(t + 4) * 256, &lds[t & 3][wave * 64]);
-            mfma_tile<K, QT, false, true>(a, b, c0, m1, m2, pend0, pend1, 32, h,
-                                          &lds[(t + 1) & 3][lane]);
+            mfma_tile<K, QT, false, true, decltype(parity)::value>(
+                a, b, decltype(parity)::value ? c1 : c0, m1, m2, pend0, pend1, 32, h,
+                &lds[(t + 1) & 3][lane]);
+        };
+        int t = 0;
+        for (; t + 2 < n_tiles; t += 2) {
+            step(t, std::integral_constant<int, 0>());
+            step(t + 1, std::integral_constant<int, 1>());
         }
-        // the last tile (its fragments are already in registers) may be partial
+        // one or two tiles are left; the last one (its fragments are already in registers
+        // when its turn comes) may be partial
         const int valid = n - 32 * (n_tiles - 1);
-        mfma_tile<K, QT, true, false>(a, b, c0, m1, m2, pend0, pend1, valid, h, nullptr);
-        fold_pending<K, QT>(m1, m2, pend0, pend1, valid, h);
+        if (t + 1 < n_tiles) {
+            step(t, std::integral_constant<int, 0>());
+            mfma_tile<K, QT, true, false, 1>(a, b, c1, m1, m2, pend0, pend1, valid, h, nullptr);
+            fold_pending<K, QT, 1>(m1, m2, pend0, pend1, valid, h);
+        } else {
+            mfma_tile<K, QT, true, false, 0>(a, b, c0, m1, m2, pend0, pend1, valid, h, nullptr);
+            fold_pending<K, QT, 0>(m1, m2, pend0, pend1, valid, h);
+        }
         // no load may still be writing LDS when the workgroup gives it back
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -294,7 +327,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ q_raw,
     }
     if (h != 0)
         return;
-    const int top = 32 * (n_tiles - 1) + 31;
+    const int top = 64 * ((n_tiles - 1) >> 1) + 63; // index field 0 = last row of the last pair
 #pragma unroll
     for (int j = 0; j < QT; j++) {
         const int64_t qi = qbase + j * 32 + r;
