@@ -50,7 +50,8 @@ MfmaPlan knn_mfma_plan_frames(int n_frames, int64_t max_nq, int64_t max_nt, int6
 // knn_mfma_expanded_bytes(nt)), the distance kernel, the merge of the splits.  d_train ==
 // nullptr: d_tx already holds the image (a resident train set), no pre-pass.  events, when
 // given (five of them), bracket the FP4 pre-pass [4, 0], the distance kernel [0, 1] and the
-// merge [1, 2]; [2, 3] is empty.
+// merge [1, 2] (empty with a single split: the distance kernel then writes the k-NN rows
+// itself); [2, 3] is empty.
 hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, const void *d_train,
                            int64_t nt, int k, int32_t index_base, void *d_tx,
                            uint32_t *d_part, int32_t *d_out_idx, int32_t *d_out_dist,

@@ -215,12 +215,22 @@ __device__ __forceinline__ void load_to_lds(const uint4 *g, uint4 *lds_wave_base
 // the FP4 image of its train rows (8 pieces of 16 bytes per row), readable for
 // MF_PAD_ROWS rows past the last one.  Output as in
 // knn_partial_body: part[split][rank][part_stride] keys local to the split.
+//
+// With a single split there is nothing to merge: out.idx != nullptr makes the kernel write
+// the final k-NN rows itself (row part_row0 + i of the outputs) instead of keys.
+struct DirectOut {
+    int32_t *idx, *dist; // nullptr: write per-split keys to `part`
+    uint8_t *keep;
+    float ratio;
+    int32_t index_base;
+};
+
 template <int K, int QT>
 __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ q_raw,
                                               const uint4 *__restrict__ tx, int64_t nq, int64_t nt,
                                               int64_t rows_per_split, uint32_t *__restrict__ part,
                                               int64_t part_row0, int64_t part_stride,
-                                              unsigned q_block, unsigned split)
+                                              unsigned q_block, unsigned split, const DirectOut &out)
 {
     __shared__ uint4 lds[4][256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -342,23 +352,43 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ q_raw,
             const uint32_t u = (uint32_t)m2[j];
             k2 = ((256u - (u >> 15)) << KNN_KEY_SHIFT) | (uint32_t)(top - (int)(u & 32767u));
         }
-        uint32_t *p1 = part + ((int64_t)split * 2) * part_stride + part_row0;
-        p1[qi] = k1;
-        p1[part_stride + qi] = k2;
+        if (out.idx == nullptr) {
+            uint32_t *p1 = part + ((int64_t)split * 2) * part_stride + part_row0;
+            p1[qi] = k1;
+            p1[part_stride + qi] = k2;
+            continue;
+        }
+        // a single split: these ARE the k-NN rows (same formats as knn_merge_body writes)
+        const uint32_t mask = (1u << KNN_KEY_SHIFT) - 1;
+        const int64_t o = part_row0 + qi;
+        const bool v1 = k1 != 0xFFFFFFFFu, v2 = k2 != 0xFFFFFFFFu;
+        const int32_t i1 = v1 ? (int32_t)(k1 & mask) + out.index_base : -1;
+        const int32_t d1 = v1 ? (int32_t)(k1 >> KNN_KEY_SHIFT) : 0x7FFFFFFF;
+        if (K == 1) {
+            out.idx[o] = i1;
+            out.dist[o] = d1;
+            continue;
+        }
+        const int32_t i2 = v2 ? (int32_t)(k2 & mask) + out.index_base : -1;
+        const int32_t d2 = v2 ? (int32_t)(k2 >> KNN_KEY_SHIFT) : 0x7FFFFFFF;
+        *reinterpret_cast<int2 *>(out.idx + 2 * o) = make_int2(i1, i2);
+        *reinterpret_cast<int2 *>(out.dist + 2 * o) = make_int2(d1, d2);
+        if (out.keep)
+            out.keep[o] = (v1 && v2 && (float)d1 < out.ratio * (float)d2) ? 1 : 0;
     }
 }
 
 template <int K, int QT>
 __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_kernel(
     const uint4 *__restrict__ q_raw, const uint4 *__restrict__ tx, int64_t nq, int64_t nt,
-    int64_t rows_per_split, uint32_t *__restrict__ part)
+    int64_t rows_per_split, uint32_t *__restrict__ part, DirectOut out)
 {
     // XCD-contiguous order of the (split, query block) space, as in knn_partial_kernel
     const unsigned X = gridDim.x, N = X * gridDim.y;
     const unsigned L = blockIdx.x + X * blockIdx.y;
     const unsigned base = N >> 3, rem = N & 7, c = L & 7;
     const unsigned nl = c * base + min(c, rem) + (L >> 3);
-    knn_mfma_body<K, QT>(q_raw, tx, nq, nt, rows_per_split, part, 0, nq, nl % X, nl / X);
+    knn_mfma_body<K, QT>(q_raw, tx, nq, nt, rows_per_split, part, 0, nq, nl % X, nl / X, out);
 }
 
 // A batch of independent matching problems (grid.z = frame), as knn_partial_frames_kernel:
@@ -374,8 +404,7 @@ template <int K, int QT>
 __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_frames_kernel(
     const uint4 *__restrict__ q_raw, const uint4 *__restrict__ tx,
     const int32_t *__restrict__ q_off, const int32_t *__restrict__ t_off, int64_t t_row0,
-    int64_t total_nq,
-    uint32_t *__restrict__ part, int xcd_chunks)
+    int64_t total_nq, uint32_t *__restrict__ part, int xcd_chunks, DirectOut out)
 {
     unsigned bx = blockIdx.x, by = blockIdx.y, f = blockIdx.z;
     if (xcd_chunks) {
@@ -396,7 +425,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void knn_mfma_frames_kernel(
     const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
 #endif
     knn_mfma_body<K, QT>(q_raw + 2 * q0, tx + 8 * (t0 - t_row0), nq, nt,
-                         mfma_rows_per_split(nt, (int)gridDim.y), part, q0, total_nq, bx, by);
+                         mfma_rows_per_split(nt, (int)gridDim.y), part, q0, total_nq, bx, by, out);
 #ifdef POSEHIP_MF_CLOCKS
     if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 3 && threadIdx.x == 0) {
         mf_clock_probe[0] = __builtin_readcyclecounter() - c0;
@@ -508,9 +537,11 @@ hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, c
         return e;
     dim3 grid((unsigned)p.q_blocks, (unsigned)p.n_splits);
     const uint4 *q4 = (const uint4 *)d_query, *t4 = (const uint4 *)d_tx;
+    const bool direct = p.n_splits == 1;
+    const DirectOut out = {direct ? d_out_idx : nullptr, d_out_dist, d_keep, ratio, index_base};
 #define POSEHIP_MF_LAUNCH(KK, QQ)                                                               \
     knn_mfma_kernel<KK, QQ><<<grid, MF_WAVES * 64, 0, stream>>>(q4, t4, nq, nt,                \
-                                                                p.rows_per_split, d_part)
+                                                                p.rows_per_split, d_part, out)
     if (p.q_tiles == 4 && k == 2)
         POSEHIP_MF_LAUNCH(2, 4);
     else if (p.q_tiles == 4)
@@ -526,8 +557,8 @@ hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, c
         return e;
     if ((e = record(events, 1, stream)) != hipSuccess)
         return e;
-    if ((e = knn_merge_launch(d_part, nq, p.n_splits, p.rows_per_split, k, index_base, d_out_idx,
-                              d_out_dist, d_keep, ratio, stream)) != hipSuccess)
+    if (!direct && (e = knn_merge_launch(d_part, nq, p.n_splits, p.rows_per_split, k, index_base,
+                                         d_out_idx, d_out_dist, d_keep, ratio, stream)) != hipSuccess)
         return e;
     if ((e = record(events, 2, stream)) != hipSuccess)
         return e;
@@ -558,9 +589,11 @@ hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const 
         return e;
     dim3 grid((unsigned)p.q_blocks, (unsigned)p.n_splits, (unsigned)n_frames);
     const uint4 *q4 = (const uint4 *)d_query, *t4 = (const uint4 *)d_tx;
+    const bool direct = p.n_splits == 1;
+    const DirectOut out = {direct ? d_out_idx : nullptr, d_out_dist, d_keep, ratio, 0};
 #define POSEHIP_MF_LAUNCH(KK, QQ)                                                               \
     knn_mfma_frames_kernel<KK, QQ><<<grid, MF_WAVES * 64, 0, stream>>>(                         \
-        q4, t4, d_q_off, d_t_off, t_begin, q_end, d_part, xcd)
+        q4, t4, d_q_off, d_t_off, t_begin, q_end, d_part, xcd, out)
     if (p.q_tiles == 4 && k == 2)
         POSEHIP_MF_LAUNCH(2, 4);
     else if (p.q_tiles == 4)
@@ -577,9 +610,10 @@ hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const 
     if ((e = record(events, 1, stream)) != hipSuccess)
         return e;
     const int64_t max_nq = p.q_blocks * (32 * p.q_tiles * MF_WAVES);
-    if ((e = knn_merge_frames_launch(d_part, d_q_off, d_t_off, q_end, max_nq, n_frames, p.n_splits,
+    if (!direct &&
+        (e = knn_merge_frames_launch(d_part, d_q_off, d_t_off, q_end, max_nq, n_frames, p.n_splits,
                                      -1, k, d_out_idx, d_out_dist, d_keep, ratio, stream)) !=
-        hipSuccess)
+            hipSuccess)
         return e;
     if ((e = record(events, 2, stream)) != hipSuccess)
         return e;
