@@ -38,12 +38,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr float MF_NONE = -65536.0f;   // stays negative under 1024 additions of 32
-#ifdef POSEHIP_MF_NOSCALE // timing experiment only: results are wrong without the scale
-static constexpr int MF_SCALE_A = 0, MF_SCALE_B = 0;
-#else
 static constexpr int MF_SCALE_A = 0x89898989; // E8M0 2^10 in every byte
 static constexpr int MF_SCALE_B = 0x7F7F7F7F; // E8M0 2^0
-#endif
 
 // ---- bit -> FP4 expansion -------------------------------------------------------
 // 8 bits -> 8 nibbles: bit i moves to bit 4 i, then nibble = 0x6 (+4.0) | bit << 3 (sign).
@@ -299,9 +295,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint4 *__restrict__ q_raw,
         // fragments of tile t, whose slot the load of tile t + 4 may overwrite.
         auto step = [&](int t, auto parity) {
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-#ifndef POSEHIP_MF_NOBARRIER // timing experiment only: racy without it
             __builtin_amdgcn_s_barrier();
-#endif
             load_to_lds(src + (int64_t)(t + 4) * 256, &lds[t & 3][wave * 64]);
             mfma_tile<K, QT, false, true, decltype(parity)::value>(
                 a, b, decltype(parity)::value ? c1 : c0, m1, m2, pend0, pend1, 32, h,
