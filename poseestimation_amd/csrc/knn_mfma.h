@@ -58,10 +58,10 @@ hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, c
                            uint8_t *d_keep, float ratio, hipStream_t stream,
                            hipEvent_t *events = nullptr);
 
-// Same contract as knn_frames_launch; [q_begin, q_end) / [t_begin, t_end) are the row
-// ranges the offset tables span (q_end rows of part / outputs are addressed).
+// Same contract as knn_frames_launch; q_end is the end of the row range the query table
+// spans (q_end rows of part / outputs are addressed), [t_begin, t_end) the train table's.
 hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const int32_t *d_q_off,
-                                  int64_t q_begin, int64_t q_end, const void *d_train,
+                                  int64_t q_end, const void *d_train,
                                   const int32_t *d_t_off, int64_t t_begin, int64_t t_end,
                                   int n_frames, int k, void *d_tx, uint32_t *d_part,
                                   int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,

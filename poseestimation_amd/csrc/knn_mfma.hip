@@ -560,7 +560,7 @@ hipError_t knn_mfma_launch(const MfmaPlan &p, const void *d_query, int64_t nq, c
 }
 
 hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const int32_t *d_q_off,
-                                  int64_t q_begin, int64_t q_end, const void *d_train,
+                                  int64_t q_end, const void *d_train,
                                   const int32_t *d_t_off, int64_t t_begin, int64_t t_end,
                                   int n_frames, int k, void *d_tx, uint32_t *d_part,
                                   int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,

@@ -790,16 +790,20 @@ struct FrameSide {
     int64_t begin, end, max_rows;
 };
 
-// Device copies of the last batch's tables, in the order of knn_frames_locked's (q, t)
-// arguments (the cross-check passes its train side as q), and their ring slot.
-const int32_t *g_frames_d_q_off = nullptr, *g_frames_d_t_off = nullptr;
-Context::OffsetSlot *g_frames_slot = nullptr;
+// Device copies of a batch's tables, in the order of knn_frames_locked's (q, t) arguments,
+// and the ring slot they travel in (its `done` event is recorded behind the k-NN launch; a
+// caller that queues more kernels reading the tables records it again behind those).
+struct FrameTables {
+    const int32_t *d_q_off = nullptr, *d_t_off = nullptr;
+    Context::OffsetSlot *slot = nullptr;
+};
 
 // k-NN of every frame's q rows among its t rows, into outputs indexed by q row; the
 // caller holds g_mu.  Picks the matrix-core or the popcount kernel by size.
 ph_status knn_frames_locked(const FrameSide &q, const FrameSide &t, int n_frames, bool uniform,
                             int k, DevBuf &part, int32_t *d_out_idx, int32_t *d_out_dist,
-                            uint8_t *d_keep, float ratio, hipStream_t st, hipEvent_t *ev)
+                            uint8_t *d_keep, float ratio, hipStream_t st, hipEvent_t *ev,
+                            FrameTables *tables = nullptr)
 {
     ph_status s;
     FrameBatch fb; // carries the device tables out of upload_frame_tables
@@ -825,7 +829,7 @@ ph_status knn_frames_locked(const FrameSide &q, const FrameSide &t, int n_frames
     if ((s = upload_frame_tables(q.offsets, t.offsets, n_frames, st, fb, slot)) != PH_OK)
         return s;
     if (mfma)
-        PH_HIP(knn_mfma_frames_launch(mp, q.d_rows, fb.d_q_off, q.begin, q.end, t.d_rows,
+        PH_HIP(knn_mfma_frames_launch(mp, q.d_rows, fb.d_q_off, q.end, t.d_rows,
                                       fb.d_t_off, t.begin, t.end, n_frames, k, g_ctx.xt.p,
                                       (uint32_t *)part.p, d_out_idx, d_out_dist, d_keep, ratio,
                                       st, ev, uniform));
@@ -835,9 +839,8 @@ ph_status knn_frames_locked(const FrameSide &q, const FrameSide &t, int n_frames
                                  ev, uniform));
     PH_HIP(hipEventRecord(slot->done, st));
     g_ctx.last_path = mfma ? 1 : 0;
-    g_frames_d_q_off = fb.d_q_off;
-    g_frames_d_t_off = fb.d_t_off;
-    g_frames_slot = slot;
+    if (tables)
+        *tables = FrameTables{fb.d_q_off, fb.d_t_off, slot};
     return PH_OK;
 }
 
@@ -915,21 +918,22 @@ ph_status ph_match_crosscheck_hamming256_frames_dev(const void *d_query, const i
     PH_HIP(g_ctx.tmp_d.reserve((size_t)fb.t_end * sizeof(int32_t)));
     PH_HIP(g_ctx.best.reserve((size_t)fb.q_end * sizeof(unsigned long long)));
     // Roles swapped: every train row finds its nearest query row of its own frame (so the
-    // device tables come back as g_frames_d_q_off = train offsets, _t_off = query offsets).
+    // device tables come back as tables.d_q_off = train offsets, d_t_off = query offsets).
+    FrameTables tables;
     FrameSide q = {d_query, q_offsets, fb.q_begin, fb.q_end, fb.max_nq};
     FrameSide t = {d_train, t_offsets, fb.t_begin, fb.t_end, fb.max_nt};
     if ((s = knn_frames_locked(t, q, n_frames, fb.uniform, 1, g_ctx.part2,
                                (int32_t *)g_ctx.tmp_i.p, (int32_t *)g_ctx.tmp_d.p, nullptr, 0.f,
-                               st, nullptr)) != PH_OK)
+                               st, nullptr, &tables)) != PH_OK)
         return s;
     // (the tables' ring slot stays busy until the resolve kernels below have run:
     // same stream, and the next call that reuses the slot waits for its event)
     PH_HIP(crosscheck_resolve_frames_launch((const int32_t *)g_ctx.tmp_i.p,
-                                            (const int32_t *)g_ctx.tmp_d.p, g_frames_d_t_off,
-                                            g_frames_d_q_off, n_frames, fb.max_nt, fb.q_begin,
+                                            (const int32_t *)g_ctx.tmp_d.p, tables.d_t_off,
+                                            tables.d_q_off, n_frames, fb.max_nt, fb.q_begin,
                                             fb.q_end, (unsigned long long *)g_ctx.best.p,
                                             d_out_idx, d_out_dist, st));
-    PH_HIP(hipEventRecord(g_frames_slot->done, st));
+    PH_HIP(hipEventRecord(tables.slot->done, st));
     return PH_OK;
 }
 

@@ -157,7 +157,7 @@ static void timeit(int64_t nq, int64_t nt, int F, int64_t splits, int q_tiles, i
         if (F == 1)
             CK(knn_mfma_launch(p, dq, nq, dt, nt, 2, 0, dtx, dpart, didx, ddist, nullptr, 0.f, 0, ev));
         else
-            CK(knn_mfma_frames_launch(p, dq, doff, 0, nq * F, dt, doff + F + 1, 0, nt * F, F, 2,
+            CK(knn_mfma_frames_launch(p, dq, doff, nq * F, dt, doff + F + 1, 0, nt * F, F, 2,
                                       dtx, dpart, didx, ddist, nullptr, 0.f, 0, ev, true));
         CK(hipEventSynchronize(ev[3]));
         float m[3], tot;
