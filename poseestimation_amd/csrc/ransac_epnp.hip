@@ -500,6 +500,23 @@ __device__ __forceinline__ void jacobi_pair2(LP<ST> At, LP<ST> W, JacobiRow<N> &
     jacobi_pair_commit<ST, N>(At, W, rb, jb, mb, changed);
 }
 
+// jacobi_pair in the straight-line form of jacobi_pair2 (one pair).
+template <int ST, int N>
+__device__ __forceinline__ void jacobi_pair_flat(LP<ST> At, LP<ST> W, JacobiRow<N> &r, int j,
+                                                 double eps, bool &changed)
+{
+    PairMath<N> m;
+    jacobi_pair_test<ST, N>(At, W, r, j, eps, m);
+    if (__builtin_amdgcn_ballot_w64(m.rotate) == 0)
+        return;
+    jacobi_pair_math<N>(r, m);
+    if (__builtin_amdgcn_ballot_w64(m.rotate & !m.plain) != 0) {
+        jacobi_pair<ST, N>(At, W, r, j, eps, changed);
+        return;
+    }
+    jacobi_pair_commit<ST, N>(At, W, r, j, m, changed);
+}
+
 // The 12 x 12 instance of jacobi_svd<ST, false>.  Row i of a pass is held in registers
 // across the inner j loop (half the LDS traffic per rotation), and passes i and i + 1 of
 // a sweep run together: at a step pass i works on (i, s) and pass i + 1 on (i + 1, s - 1),
@@ -507,10 +524,10 @@ __device__ __forceinline__ void jacobi_pair2(LP<ST> At, LP<ST> W, JacobiRow<N> &
 // rows.  Pairs on disjoint rows commute exactly (each rotation reads and writes its own
 // two rows and norms only), so every pair performs the operations it performs in the
 // cyclic order and the results are bit-identical to the generic routine.
-template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
+// W[i] = squared norm of row i (the state the sweeps start from).
+template <int ST> __device__ __forceinline__ void jacobi_init_norms_12(LP<ST> At, LP<ST> W)
 {
     constexpr int N = 12;
-    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
     for (int i = 0; i < N; i++) {
         double sd = 0;
 #pragma unroll
@@ -520,6 +537,15 @@ template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
         }
         W[i] = sd;
     }
+}
+
+template <int ST> __device__ void jacobi_finish_12(LP<ST> At, LP<ST> W);
+
+template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
+{
+    constexpr int N = 12;
+    const double eps = DBL_EPSILON * 10;
+    jacobi_init_norms_12<ST>(At, W);
     for (int iter = 0; iter < 30; iter++) {
         bool changed = false;
         // Passes i and i + 1 run together, pass i + 1 one partner row behind pass i.
@@ -543,6 +569,14 @@ template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
         if (!changed)
             break;
     }
+    jacobi_finish_12<ST>(At, W);
+}
+
+// What follows the sweeps: singular values, descending order, completion of zero rows.
+template <int ST> __device__ void jacobi_finish_12(LP<ST> At, LP<ST> W)
+{
+    constexpr int N = 12;
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
     for (int i = 0; i < N; i++) {
         double sd = 0;
 #pragma unroll
@@ -601,6 +635,103 @@ template <int ST> __device__ void jacobi_svd_12(LP<ST> At, LP<ST> W)
         for (int k = 0; k < N; k++)
             At[i * N + k] *= s;
     }
+}
+
+// Orders the LDS traffic of the lanes of one wave: what any lane wrote before this point
+// is what every lane reads after it (the LDS serves a wave's instructions in order; this
+// keeps the compiler from moving accesses across the point).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The sweeps of jacobi_svd_12 with G lanes per matrix.  In the cyclic order pair (i, j)
+// depends only on the earlier pairs that touch row i or row j, which are (i, j - 1) and
+// (i - 1, j) and what precedes those; so all pairs with i + j - 1 == T can run once step
+// T - 1 is done, they touch 2 * count different rows, and each performs exactly the
+// operations it performs in the sequential order: a sweep is 21 steps of 1..6 independent
+// pairs instead of 66 pairs in a row.  The next sweep starts 12 steps after this one, not
+// 21: its pair (i, j) then runs at step i + j + 11 of this sweep, after (j, 11) at step
+// j + 10 and (i, 11) at step i + 10, the last pairs here that touch its rows, and the two
+// sweeps' pairs of one step are on different rows (the new sweep's are <= T + 1, the old
+// one's >= T + 2).  Steady state: 5 or 6 independent pairs per step, 12 steps per sweep.
+// A sweep that rotates nothing ends the decomposition; the first 9 steps of its
+// successor have run by then, on rows that sweep has left as they were, so they repeat
+// its tests and rotate nothing either: the result is that of the sequential order, bit
+// for bit.  At most 30 sweeps, as there.
+// The lanes g = 0..G-1 that share a matrix take the pairs of a step G at a time.  The
+// matrix and the row norms are in LDS (At, W: the same addresses in every lane of a
+// group).  Lane `hl + HPW * g` is member g of group hl; all members of a group must
+// enter together.  OVERLAP = false starts a sweep only when the one before is complete
+// (period 21): with 2 or 4 lanes per matrix the overlap saves 7 % of the rounds but fewer
+// rounds are then free of rotations in every lane of the wave, and it measured slower.
+template <int ST, int G, int HPW, bool OVERLAP>
+__device__ void jacobi_sweeps_12_shared(LP<ST> At, LP<ST> W, int g, int hl)
+{
+    constexpr int N = 12, MAX_SWEEPS = 30, LAST = 2 * N - 4, PERIOD = OVERLAP ? N : LAST + 1;
+    const double eps = DBL_EPSILON * 10;
+    unsigned long long group = 0;
+    for (int m = 0; m < G; m++)
+        group |= 1ull << (m * HPW);
+    bool rot_old = false, rot_new = false; // a rotation in sweep s - 1 / in sweep s
+    for (int s = 0; s <= MAX_SWEEPS; s++) {
+        for (int T0 = 0; T0 < PERIOD; T0++) {
+            // sweep s is at its step T0, sweep s - 1 at its step T0 + PERIOD
+            const int T1 = T0 + PERIOD;
+            const int lo0 = T0 > N - 2 ? T0 - (N - 2) : 0, lo1 = T1 - (N - 2);
+            const int c0 = s < MAX_SWEEPS ? (T0 >> 1) - lo0 + 1 : 0;
+            const int c1 = OVERLAP && s > 0 && T1 <= LAST ? (T1 >> 1) - lo1 + 1 : 0;
+            for (int q0 = 0; q0 < c0 + c1; q0 += G) {
+                const int q = q0 + g;
+                if (q < c0 + c1) {
+                    const bool old = OVERLAP && q >= c0;
+                    const int i = old ? lo1 + q - c0 : lo0 + q;
+                    const int j = (old ? T1 : T0) + 1 - i;
+                    const LP<ST> Ai = At + i * N;
+                    JacobiRow<N> r;
+                    r.load(Ai, W[i]);
+                    jacobi_pair_flat<ST, N>(At, W, r, j, eps, r.dirty);
+                    r.store(Ai, W[i]);
+                    rot_old |= old & r.dirty;
+                    rot_new |= !old & r.dirty;
+                }
+                wave_sync();
+            }
+            if (OVERLAP && s > 0 && T1 == LAST) { // sweep s - 1 is complete
+                if (s == MAX_SWEEPS || (__builtin_amdgcn_ballot_w64(rot_old) >> hl & group) == 0)
+                    return;
+            }
+        }
+        if (!OVERLAP) { // sweep s is complete
+            if (s == MAX_SWEEPS - 1 || (__builtin_amdgcn_ballot_w64(rot_new) >> hl & group) == 0)
+                return;
+        }
+        rot_old = rot_new;
+        rot_new = false;
+    }
+}
+
+// jacobi_svd_12 for a wave whose 64 lanes hold identical copies of the matrix (At, W in
+// each lane's own arrays): the sweeps run once on a compact copy in `sh`
+// (COOP_SH_DOUBLES doubles of LDS that no lane's arrays overlap), six lanes taking the
+// up to six independent pairs of a step.
+constexpr int COOP_SH_DOUBLES = 160;
+template <int ST> __device__ void jacobi_svd_12_coop(LP<ST> At, LP<ST> W, double *sh, int lane)
+{
+    jacobi_init_norms_12<ST>(At, W);
+    for (int e = lane; e < 144; e += 64)
+        sh[e] = At[e];
+    if (lane < 12)
+        sh[144 + lane] = W[lane];
+    wave_sync();
+    jacobi_sweeps_12_shared<1, 64, 1, true>(LP<1>{sh}, LP<1>{sh + 144}, lane, 0);
+    for (int e = 0; e < 144; e++)
+        At[e] = sh[e];
+    for (int e = 0; e < 12; e++)
+        W[e] = sh[144 + e];
+    jacobi_finish_12<ST>(At, W);
 }
 
 // A lane's LDS arrays (offsets in doubles; LDS_DOUBLES per hypothesis).  Lifetimes
@@ -1157,20 +1288,46 @@ __device__ double compute_R_and_t(const Points &P, EpnpState &e, const EpnpLds<S
     return sum2 / n;
 }
 
-// epnp::compute_pose on the correspondences P.
-template <int ST>
-__device__ void epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3], double t[3])
+// How the lanes of a wave share the 12 x 12 decomposition inside epnp_pose.
+enum PoseMode {
+    POSE_LANE,    // every lane solves its own problem by itself
+    POSE_HELPED,  // lanes ST*g + hl, g = 0..64/ST-1, serve problem hl: member 0 runs the
+                  // solve, the others join it for the Jacobi sweeps only
+    POSE_WAVE     // all 64 lanes run the same solve on identical private copies (refit)
+};
+
+// epnp::compute_pose on the correspondences P.  Returns false in the helper lanes of
+// POSE_HELPED, which hold no result.  lane / sh: see the modes (sh = the compact LDS
+// area of jacobi_svd_12_coop, POSE_WAVE only).
+template <int ST, PoseMode MODE = POSE_LANE>
+__device__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3], double t[3],
+                          int lane = 0, double *sh = nullptr)
 {
     EpnpState e;
-    PNP_STAMP(0);
-    choose_control_points(P, e, S);
-    PNP_STAMP(1);
-    compute_basis_inverse(e, S);
-    PNP_STAMP(2);
-    accumulate_mtm(P, e, S);
-    PNP_STAMP(3);
+    const int member = MODE == POSE_HELPED ? lane / ST : 0;
+    if (member == 0) {
+        PNP_STAMP(0);
+        choose_control_points(P, e, S);
+        PNP_STAMP(1);
+        compute_basis_inverse(e, S);
+        PNP_STAMP(2);
+        accumulate_mtm(P, e, S);
+        PNP_STAMP(3);
+    }
     // MtM is symmetric, so it is its own transposed copy; EPnP reads only U
-    jacobi_svd_12<ST>(S.ut, S.w);
+    if constexpr (MODE == POSE_WAVE) {
+        jacobi_svd_12_coop<ST>(S.ut, S.w, sh, lane);
+    } else if constexpr (MODE == POSE_HELPED) {
+        if (member == 0)
+            jacobi_init_norms_12<ST>(S.ut, S.w);
+        wave_sync();
+        jacobi_sweeps_12_shared<ST, 64 / ST, ST, false>(S.ut, S.w, member, lane % ST);
+        if (member != 0)
+            return false;
+        jacobi_finish_12<ST>(S.ut, S.w);
+    } else {
+        jacobi_svd_12<ST>(S.ut, S.w);
+    }
     PNP_STAMP(4);
     NullRows<ST> N;
     detach_null_rows(S, N);
@@ -1202,6 +1359,7 @@ __device__ void epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3],
             }
         }
     }
+    return true;
 }
 
 // cv::Rodrigues matrix -> vector (R re-orthonormalised by SVD first).
@@ -1316,7 +1474,8 @@ __device__ inline Points make_points(const float *obj, const float *img, const i
 } // namespace
 
 // Solve kernel: lane l < HPW of workgroup b solves hypothesis h = b*HPW + l (EPnP
-// on rows subsets[5h .. 5h+5)) and writes its model (rvec, tvec) to models[6h..].
+// on rows subsets[5h .. 5h+5)) and writes its model (rvec, tvec) to models[6h..]; the
+// lanes l + HPW, l + 2*HPW, ... of the wave join it for the Jacobi sweeps (POSE_HELPED).
 // Dynamic LDS: HPW * LDS_DOUBLES doubles.
 // A batch holds n_problems independent problems of hyp_per_problem hypotheses
 // each; problem p owns the correspondence rows [begins[p], ends[p]) (begins ==
@@ -1330,15 +1489,16 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(const float *__restric
                                                           double *__restrict__ models)
 {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const int h = h0 + blockIdx.x * HPW + lane;
-    if (lane >= HPW || h >= n_hyp)
+    const int lane = threadIdx.x, hl = lane % HPW;
+    const int h = h0 + blockIdx.x * HPW + hl;
+    if (h >= n_hyp)
         return;
-    const EpnpLds<HPW> S(lds + lane);
+    const EpnpLds<HPW> S(lds + hl);
     const int64_t row0 = begins ? begins[h / hyp_per_problem] : 0;
     const Points P = make_points(obj + 3 * row0, img + 2 * row0, subsets + (int64_t)h * 5, 5, K);
     double R[3][3], t[3], r[3];
-    epnp_pose(P, S, R, t);
+    if (!epnp_pose<HPW, HPW < 64 ? POSE_HELPED : POSE_LANE>(P, S, R, t, lane))
+        return;
     rodrigues_mat_to_vec(S, R, r);
     PNP_STAMP(15);
     double *m = models + (int64_t)h * 6;
@@ -1418,7 +1578,7 @@ __global__ __launch_bounds__(64) void epnp_solve_kernel(const float *__restrict_
         P.step = 64;
     }
     double R[3][3], t[3], r[3];
-    epnp_pose(P, S, R, t);
+    epnp_pose<64, POSE_WAVE>(P, S, R, t, lane, lds + 64 * LDS_DOUBLES);
     rodrigues_mat_to_vec(S, R, r);
     if (lane == 0) {
         model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
@@ -1467,7 +1627,7 @@ __global__ __launch_bounds__(64) void epnp_solve_batched_kernel(
         P.step = 64;
     }
     double R[3][3], t[3], r[3];
-    epnp_pose(P, S, R, t);
+    epnp_pose<64, POSE_WAVE>(P, S, R, t, lane, lds + 64 * LDS_DOUBLES);
     rodrigues_mat_to_vec(S, R, r);
     if (lane == 0) {
         double *model = models + (int64_t)b * 6;
@@ -1564,7 +1724,7 @@ hipError_t inlier_mask_launch(const float *d_obj, const float *d_img, int n, Cam
 hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,
                              CameraK K, double *d_model, hipStream_t stream)
 {
-    const size_t lds_bytes = (size_t)64 * LDS_DOUBLES * sizeof(double);
+    const size_t lds_bytes = ((size_t)64 * LDS_DOUBLES + COOP_SH_DOUBLES) * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void *)epnp_solve_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
@@ -1596,7 +1756,7 @@ hipError_t epnp_solve_batched_launch(const float *d_obj, const float *d_img,
 {
     if (n_problems <= 0)
         return hipSuccess;
-    const size_t lds_bytes = (size_t)64 * LDS_DOUBLES * sizeof(double);
+    const size_t lds_bytes = ((size_t)64 * LDS_DOUBLES + COOP_SH_DOUBLES) * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void *)epnp_solve_batched_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
+#include <cstring>
 #include <random>
 #include <vector>
 __device__ long long g_pnp_stamps[32];
@@ -34,6 +35,27 @@ int main(int argc, char **argv)
     CK(hipMemcpy(d_sub, sub.data(), sub.size() * 4, hipMemcpyHostToDevice));
     CameraK K{f, f, 400, 300};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (argc > 1 && !strcmp(argv[1], "refit")) { // refit [n]: per-phase cycles of the one-wave refit kernel
+        const int m = argc > 2 ? atoi(argv[2]) : 354;
+        std::vector<int32_t> id(m);
+        for (int i = 0; i < m; i++) id[i] = i;
+        int32_t *d_id; double *d_model;
+        CK(hipMalloc(&d_id, m * 4)); CK(hipMalloc(&d_model, 48));
+        CK(hipMemcpy(d_id, id.data(), m * 4, hipMemcpyHostToDevice));
+        for (int r = 0; r < 3; r++) {
+            CK(hipEventRecord(e0));
+            CK(epnp_solve_launch(d_obj, d_img, d_id, m, K, d_model, 0));
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("refit on %d points: %.1f us\n", m, ms * 1e3);
+        }
+        long long st[32];
+        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pnp_stamps), sizeof(st)));
+        const char *names[] = {"", "control points", "basis inverse", "MtM", "jacobi 12x12", "L_6x10", "betas1", "gn1", "Rt1", "betas2", "gn2", "Rt2", "betas3", "gn3", "Rt3"};
+        for (int k = 1; k <= 14; k++) printf("%-16s %9lld cycles\n", names[k], st[k] - st[k - 1]);
+        printf("total            %9lld cycles\n", st[14] - st[0]);
+        return 0;
+    }
     if (argc > 3) { // H HPW LDS_KB: solve kernel only, workgroup LDS padded to LDS_KB (spreads the waves)
         const int hpw = atoi(argv[2]);
         const size_t lds = (size_t)atoi(argv[3]) * 1024;
