@@ -143,6 +143,80 @@ template <int ST> struct LP {
     }
 };
 
+// Orders the LDS traffic of the lanes of one wave: what any lane wrote before this point
+// is what every lane reads after it (the LDS serves a wave's instructions in order; this
+// keeps the compiler from moving accesses across the point).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One pair of a fixed-size decomposition (rows i and j of At, length M; rows of Vt, length
+// N), exactly as JacobiSVDImpl_ states it.  True if the pair was rotated.
+template <int ST, bool WITH_V, int M, int N>
+__device__ __forceinline__ bool jacobi_small_pair(LP<ST> At, LP<ST> W, LP<ST> Vt, int i, int j,
+                                                  double eps)
+{
+    const LP<ST> Ai = At + i * M, Aj = At + j * M;
+    double a = W[i], p = 0, b = W[j], c, s;
+    double ai[M], aj[M];
+#pragma unroll
+    for (int k = 0; k < M; k++) {
+        ai[k] = Ai[k];
+        aj[k] = Aj[k];
+    }
+#pragma unroll
+    for (int k = 0; k < M; k++)
+        p += ai[k] * aj[k];
+    if (fabs(p) <= eps * sqrt(a * b))
+        return false;
+    p *= 2;
+    const double beta = a - b, gamma = hypot_cr(p, beta);
+    jacobi_rotation(p, beta, gamma, c, s);
+    a = b = 0;
+#pragma unroll
+    for (int k = 0; k < M; k++) {
+        const double t0 = c * ai[k] + s * aj[k];
+        const double t1 = -s * ai[k] + c * aj[k];
+        Ai[k] = t0;
+        Aj[k] = t1;
+        a += t0 * t0;
+        b += t1 * t1;
+    }
+    W[i] = a;
+    W[j] = b;
+    if (WITH_V) {
+        const LP<ST> Vi = Vt + i * N, Vj = Vt + j * N;
+        double vi[N], vj[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            vi[k] = Vi[k];
+            vj[k] = Vj[k];
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            Vi[k] = c * vi[k] + s * vj[k];
+            Vj[k] = -s * vi[k] + c * vj[k];
+        }
+    }
+    return true;
+}
+
+// Lanes of a wave that share one problem's LDS copy (see PoseMode::POSE_HELPED): lane
+// `first + stride * g` is member g of `count`.  count == 1: the lane is on its own.
+struct LaneGroup {
+    int member = 0, first = 0, stride = 64, count = 1;
+    __device__ bool any(bool x) const // over the members of this lane's group
+    {
+        unsigned long long mask = 0;
+        for (int m = 0; m < count; m++)
+            mask |= 1ull << (first + m * stride);
+        return (__builtin_amdgcn_ballot_w64(x) & mask) != 0;
+    }
+};
+
 // One-sided Jacobi SVD on the n rows of At (length m each); rotations
 // accumulate in Vt (n x n).  On exit the rows of At are the left singular
 // vectors, W descending.  Same sweep order, thresholds and zero-row completion
@@ -151,8 +225,13 @@ template <int ST> struct LP {
 // M, N > 0 fix the sizes at compile time (astep == M, vstep == N): the rows of a pair are
 // then read into registers in one batch and the loops over their elements unroll, instead
 // of one LDS round trip per element.  Same operations in the same order either way.
+// grp.count > 1 (fixed sizes only): the members of the group, which all make this call
+// on the same arrays, split the sweeps: the pairs (i, j) with i + j - 1 == T touch
+// different rows and depend only on pairs of earlier T, so a sweep runs as 2N - 3 steps
+// whose pairs go to different members, each pair with the operations of the cyclic order.
 template <int ST, bool WITH_V, int M = 0, int N = 0>
-__device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep, int m, int n)
+__device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep, int m, int n,
+                           LaneGroup grp = LaneGroup())
 {
     const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
     const int max_iter = m > 30 ? m : 30;
@@ -176,56 +255,37 @@ __device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep,
             Vt[i * vstep + i] = 1;
         }
     }
-    for (int iter = 0; iter < max_iter; iter++) {
+    bool swept = false;
+    if constexpr (M > 0 && N > 3) {
+        if (grp.count > 1) {
+            wave_sync();
+            for (int iter = 0; iter < max_iter; iter++) {
+                bool changed = false;
+                for (int T = 0; T <= 2 * N - 4; T++) {
+                    const int lo = T > N - 2 ? T - (N - 2) : 0, hi = T >> 1;
+                    for (int i0 = lo; i0 <= hi; i0 += grp.count) {
+                        const int i = i0 + grp.member;
+                        if (i <= hi)
+                            changed |= jacobi_small_pair<ST, WITH_V, M, N>(At, W, Vt, i, T + 1 - i, eps);
+                        wave_sync();
+                    }
+                }
+                if (!grp.any(changed))
+                    break;
+            }
+            swept = true;
+        }
+    }
+    for (int iter = 0; iter < max_iter && !swept; iter++) {
         bool changed = false;
         for (int i = 0; i < n - 1; i++)
             for (int j = i + 1; j < n; j++) {
-                const LP<ST> Ai = At + i * astep, Aj = At + j * astep;
-                double a = W[i], p = 0, b = W[j];
                 if constexpr (M > 0) {
-                    double ai[M], aj[M];
-#pragma unroll
-                    for (int k = 0; k < M; k++) {
-                        ai[k] = Ai[k];
-                        aj[k] = Aj[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < M; k++)
-                        p += ai[k] * aj[k];
-                    if (fabs(p) <= eps * sqrt(a * b))
-                        continue;
-                    p *= 2;
-                    const double beta = a - b, gamma = hypot_cr(p, beta);
-                    jacobi_rotation(p, beta, gamma, c, s);
-                    a = b = 0;
-#pragma unroll
-                    for (int k = 0; k < M; k++) {
-                        const double t0 = c * ai[k] + s * aj[k];
-                        const double t1 = -s * ai[k] + c * aj[k];
-                        Ai[k] = t0;
-                        Aj[k] = t1;
-                        a += t0 * t0;
-                        b += t1 * t1;
-                    }
-                    W[i] = a;
-                    W[j] = b;
-                    changed = true;
-                    if (WITH_V) {
-                        const LP<ST> Vi = Vt + i * N, Vj = Vt + j * N;
-                        double vi[N], vj[N];
-#pragma unroll
-                        for (int k = 0; k < N; k++) {
-                            vi[k] = Vi[k];
-                            vj[k] = Vj[k];
-                        }
-#pragma unroll
-                        for (int k = 0; k < N; k++) {
-                            Vi[k] = c * vi[k] + s * vj[k];
-                            Vj[k] = -s * vi[k] + c * vj[k];
-                        }
-                    }
+                    changed |= jacobi_small_pair<ST, WITH_V, M, N>(At, W, Vt, i, j, eps);
                     continue;
                 }
+                const LP<ST> Ai = At + i * astep, Aj = At + j * astep;
+                double a = W[i], p = 0, b = W[j];
                 for (int k = 0; k < m; k++)
                     p += Ai[k] * Aj[k];
                 if (fabs(p) <= eps * sqrt(a * b))
@@ -500,21 +560,34 @@ __device__ __forceinline__ void jacobi_pair2(LP<ST> At, LP<ST> W, JacobiRow<N> &
     jacobi_pair_commit<ST, N>(At, W, rb, jb, mb, changed);
 }
 
-// jacobi_pair in the straight-line form of jacobi_pair2 (one pair).
+// One pair with both rows in LDS, in the straight-line form of jacobi_pair2; the rotated
+// rows go straight back to LDS.  True if this lane's pair was rotated.
 template <int ST, int N>
-__device__ __forceinline__ void jacobi_pair_flat(LP<ST> At, LP<ST> W, JacobiRow<N> &r, int j,
-                                                 double eps, bool &changed)
+__device__ __forceinline__ bool jacobi_pair_lds(LP<ST> At, LP<ST> W, int i, int j, double eps)
 {
+    const LP<ST> Ai = At + i * N, Aj = At + j * N;
+    JacobiRow<N> r;
+    r.load(Ai, W[i]);
     PairMath<N> m;
     jacobi_pair_test<ST, N>(At, W, r, j, eps, m);
     if (__builtin_amdgcn_ballot_w64(m.rotate) == 0)
-        return;
+        return false;
     jacobi_pair_math<N>(r, m);
-    if (__builtin_amdgcn_ballot_w64(m.rotate & !m.plain) != 0) {
-        jacobi_pair<ST, N>(At, W, r, j, eps, changed);
-        return;
+    if (__builtin_amdgcn_ballot_w64(m.rotate & !m.plain) != 0) { // hypot's special ranges
+        jacobi_pair<ST, N>(At, W, r, j, eps, r.dirty);
+        r.store(Ai, W[i]);
+        return r.dirty;
     }
-    jacobi_pair_commit<ST, N>(At, W, r, j, m, changed);
+    if (m.rotate) {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            Ai[k] = m.nv[k];
+            Aj[k] = m.nj[k];
+        }
+        W[i] = m.na;
+        W[j] = m.nb;
+    }
+    return m.rotate;
 }
 
 // The 12 x 12 instance of jacobi_svd<ST, false>.  Row i of a pass is held in registers
@@ -637,16 +710,6 @@ template <int ST> __device__ void jacobi_finish_12(LP<ST> At, LP<ST> W)
     }
 }
 
-// Orders the LDS traffic of the lanes of one wave: what any lane wrote before this point
-// is what every lane reads after it (the LDS serves a wave's instructions in order; this
-// keeps the compiler from moving accesses across the point).
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // The sweeps of jacobi_svd_12 with G lanes per matrix.  In the cyclic order pair (i, j)
 // depends only on the earlier pairs that touch row i or row j, which are (i, j - 1) and
 // (i - 1, j) and what precedes those; so all pairs with i + j - 1 == T can run once step
@@ -689,13 +752,9 @@ __device__ void jacobi_sweeps_12_shared(LP<ST> At, LP<ST> W, int g, int hl)
                     const bool old = OVERLAP && q >= c0;
                     const int i = old ? lo1 + q - c0 : lo0 + q;
                     const int j = (old ? T1 : T0) + 1 - i;
-                    const LP<ST> Ai = At + i * N;
-                    JacobiRow<N> r;
-                    r.load(Ai, W[i]);
-                    jacobi_pair_flat<ST, N>(At, W, r, j, eps, r.dirty);
-                    r.store(Ai, W[i]);
-                    rot_old |= old & r.dirty;
-                    rot_new |= !old & r.dirty;
+                    const bool rotated = jacobi_pair_lds<ST, N>(At, W, i, j, eps);
+                    rot_old |= old & rotated;
+                    rot_new |= !old & rotated;
                 }
                 wave_sync();
             }
@@ -775,14 +834,15 @@ template <int ST> __device__ void svd_small_square(const EpnpLds<ST> &S, int n)
 
 // cv::solve(A, b, x, DECOMP_SVD) with A (m x n) already TRANSPOSED in S.sa (n x m).
 template <int ST>
-__device__ void solve_svd(const EpnpLds<ST> &S, int m, int n, const double *b, double *x)
+__device__ void solve_svd(const EpnpLds<ST> &S, int m, int n, const double *b, double *x,
+                          LaneGroup grp = LaneGroup())
 {
     if (m == 6 && n == 4)
-        jacobi_svd<ST, true, 6, 4>(S.sa, 6, S.sw, S.sv, 4, 6, 4);
+        jacobi_svd<ST, true, 6, 4>(S.sa, 6, S.sw, S.sv, 4, 6, 4, grp);
     else if (m == 6 && n == 3)
         jacobi_svd<ST, true, 6, 3>(S.sa, 6, S.sw, S.sv, 3, 6, 3);
     else if (m == 6 && n == 5)
-        jacobi_svd<ST, true, 6, 5>(S.sa, 6, S.sw, S.sv, 5, 6, 5);
+        jacobi_svd<ST, true, 6, 5>(S.sa, 6, S.sw, S.sv, 5, 6, 5, grp);
     else
         jacobi_svd<ST, true>(S.sa, m, S.sw, S.sv, n, m, n);
     double threshold = 0;
@@ -1048,7 +1108,8 @@ template <int ST> __device__ void compute_L_6x10(const NullRows<ST> &N, LP<ST> l
 
 // betas10 = [B11 B12 B22 B13 B23 B33 B14 B24 B34 B44]
 template <int ST>
-__device__ void find_betas_approx(int which, const EpnpLds<ST> &S, const double *rho, double *betas)
+__device__ void find_betas_approx(int which, const EpnpLds<ST> &S, const double *rho, double *betas,
+                                  LaneGroup grp = LaneGroup())
 {
     const LP<ST> l = S.l;
     double b5[5];
@@ -1059,7 +1120,7 @@ __device__ void find_betas_approx(int which, const EpnpLds<ST> &S, const double 
             S.sa[2 * 6 + i] = l[10 * i + 3];
             S.sa[3 * 6 + i] = l[10 * i + 6];
         }
-        solve_svd(S, 6, 4, rho, b5);
+        solve_svd(S, 6, 4, rho, b5, grp);
         if (b5[0] < 0) {
             betas[0] = sqrt(-b5[0]);
             betas[1] = -b5[1] / betas[0];
@@ -1077,7 +1138,7 @@ __device__ void find_betas_approx(int which, const EpnpLds<ST> &S, const double 
     for (int i = 0; i < 6; i++)
         for (int j = 0; j < nc; j++)
             S.sa[j * 6 + i] = l[10 * i + j];
-    solve_svd(S, 6, nc, rho, b5);
+    solve_svd(S, 6, nc, rho, b5, grp);
     if (b5[0] < 0) {
         betas[0] = sqrt(-b5[0]);
         betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
@@ -1291,13 +1352,14 @@ __device__ double compute_R_and_t(const Points &P, EpnpState &e, const EpnpLds<S
 // How the lanes of a wave share the 12 x 12 decomposition inside epnp_pose.
 enum PoseMode {
     POSE_LANE,    // every lane solves its own problem by itself
-    POSE_HELPED,  // lanes ST*g + hl, g = 0..64/ST-1, serve problem hl: member 0 runs the
-                  // solve, the others join it for the Jacobi sweeps only
+    POSE_HELPED,  // lanes ST*g + hl, g = 0..64/ST-1, serve problem hl: all of them run the
+                  // solve (same instructions, same LDS copy, identical values) and split
+                  // the independent Jacobi pairs and the independent candidates
     POSE_WAVE     // all 64 lanes run the same solve on identical private copies (refit)
 };
 
-// epnp::compute_pose on the correspondences P.  Returns false in the helper lanes of
-// POSE_HELPED, which hold no result.  lane / sh: see the modes (sh = the compact LDS
+// epnp::compute_pose on the correspondences P.  Returns true in the lane that reports
+// the result (one per problem).  lane / sh: see the modes (sh = the compact LDS
 // area of jacobi_svd_12_coop, POSE_WAVE only).
 template <int ST, PoseMode MODE = POSE_LANE>
 __device__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3], double t[3],
@@ -1305,25 +1367,20 @@ __device__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3],
 {
     EpnpState e;
     const int member = MODE == POSE_HELPED ? lane / ST : 0;
-    if (member == 0) {
-        PNP_STAMP(0);
-        choose_control_points(P, e, S);
-        PNP_STAMP(1);
-        compute_basis_inverse(e, S);
-        PNP_STAMP(2);
-        accumulate_mtm(P, e, S);
-        PNP_STAMP(3);
-    }
+    PNP_STAMP(0);
+    choose_control_points(P, e, S);
+    PNP_STAMP(1);
+    compute_basis_inverse(e, S);
+    PNP_STAMP(2);
+    accumulate_mtm(P, e, S);
+    PNP_STAMP(3);
     // MtM is symmetric, so it is its own transposed copy; EPnP reads only U
     if constexpr (MODE == POSE_WAVE) {
         jacobi_svd_12_coop<ST>(S.ut, S.w, sh, lane);
     } else if constexpr (MODE == POSE_HELPED) {
-        if (member == 0)
-            jacobi_init_norms_12<ST>(S.ut, S.w);
+        jacobi_init_norms_12<ST>(S.ut, S.w);
         wave_sync();
         jacobi_sweeps_12_shared<ST, 64 / ST, ST, false>(S.ut, S.w, member, lane % ST);
-        if (member != 0)
-            return false;
         jacobi_finish_12<ST>(S.ut, S.w);
     } else {
         jacobi_svd_12<ST>(S.ut, S.w);
@@ -1340,6 +1397,80 @@ __device__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3],
     rho[3] = dist2(e.cws[1], e.cws[2]);
     rho[4] = dist2(e.cws[1], e.cws[3]);
     rho[5] = dist2(e.cws[2], e.cws[3]);
+    if constexpr (MODE == POSE_HELPED) {
+        // The three candidates (beta initialisations) are independent of one another
+        // after find_betas_approx, and Gauss-Newton and the pose step are the same code
+        // for each: the members of a group take different candidates at once.  L stays
+        // where it is while Gauss-Newton runs, so two 6 x 4 matrices fit beside it;
+        // the pose step needs 21 doubles per candidate and L is dead by then.
+        constexpr int G = 64 / ST;
+        double betas[3][4];
+        const LaneGroup grp{member, lane % ST, ST, G};
+        find_betas_approx(1, S, rho, betas[0], grp);
+        PNP_STAMP(6);
+        find_betas_approx(2, S, rho, betas[1], grp);
+        PNP_STAMP(7);
+        find_betas_approx(3, S, rho, betas[2], grp);
+        PNP_STAMP(8);
+        wave_sync();
+        {
+            const bool second = member & 1;
+            EpnpLds<ST> Sm = S;
+            Sm.ga = S.ga + (second ? 24 : 0);
+            double b[4];
+            for (int k = 0; k < 4; k++)
+                b[k] = second ? betas[1][k] : betas[0][k];
+            gauss_newton(Sm, rho, b);
+            // every member needs every candidate's betas for the pose step
+            for (int k = 0; k < 4; k++) {
+                const double other = __shfl_xor(b[k], ST, 64);
+                betas[0][k] = second ? other : b[k];
+                betas[1][k] = second ? b[k] : other;
+            }
+            PNP_STAMP(9);
+            wave_sync();
+            gauss_newton(S, rho, betas[2]);
+            PNP_STAMP(10);
+            wave_sync();
+        }
+        // pose step: candidates per round
+        constexpr int PER_ROUND = G >= 3 ? 3 : 2;
+        const LP<ST> res = S.ut + 64; // 3 x 13 results, clear of the 3 x 21 scratch doubles
+        for (int c0 = 0; c0 < 3; c0 += PER_ROUND) {
+            const int slot = member % PER_ROUND, c = c0 + slot < 3 ? c0 + slot : c0;
+            EpnpLds<ST> Sm = S;
+            Sm.sa = S.ut + 21 * (c - c0);
+            Sm.sv = Sm.sa + 9;
+            Sm.sw = Sm.sv + 9;
+            double b[4], Rc[3][3], tc[3];
+            for (int k = 0; k < 4; k++)
+                b[k] = c == 0 ? betas[0][k] : c == 1 ? betas[1][k] : betas[2][k];
+            const double err = compute_R_and_t(P, e, Sm, N, b, Rc, tc);
+            const LP<ST> out = res + 13 * c;
+            out[0] = err;
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++)
+                    out[1 + 3 * i + j] = Rc[i][j];
+                out[10 + i] = tc[i];
+            }
+            PNP_STAMP(11 + c0 / PER_ROUND);
+        }
+        wave_sync();
+        // N = 1; if (err2 < err1) N = 2; if (err3 < err[N]) N = 3
+        int best = 0;
+        if (res[13] < res[0])
+            best = 1;
+        if (res[26] < res[13 * best])
+            best = 2;
+        const LP<ST> win = res + 13 * best;
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++)
+                R[i][j] = win[1 + 3 * i + j];
+            t[i] = win[10 + i];
+        }
+        wave_sync();
+        return member == 0;
+    }
     double best_err = 0;
     for (int c = 1; c <= 3; c++) {
         double betas[4], Rc[3][3], tc[3];

@@ -104,7 +104,9 @@ int main(int argc, char **argv)
     }
     long long st[32];
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pnp_stamps), sizeof(st)));
-    const char *names[] = {"", "control points", "basis inverse", "MtM", "jacobi 12x12", "L_6x10", "betas1", "gn1", "Rt1", "betas2", "gn2", "Rt2", "betas3", "gn3", "Rt3", "rodrigues"};
+    // hypothesis kernels: the candidates' Gauss-Newton and pose steps run side by side in the lanes of a group
+    const char *names[] = {"", "control points", "basis inverse", "MtM", "jacobi 12x12", "L_6x10", "betas1", "betas2", "betas3", "gn 1|2", "gn 3", "Rt round 1", "Rt round 2", "-", "-", "rodrigues"};
+    for (int k = 1; k <= 15; k++) if (st[k] == 0) st[k] = st[k - 1]; // stamps this mode does not write
     for (int k = 1; k <= 15; k++) printf("%-16s %9lld cycles\n", names[k], st[k] - st[k - 1]);
     printf("total            %9lld cycles\n", st[15] - st[0]);
     std::vector<int32_t> c(H); CK(hipMemcpy(c.data(), d_counts, H * 4, hipMemcpyDeviceToHost));
