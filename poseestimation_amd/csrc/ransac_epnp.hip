@@ -126,10 +126,14 @@ __device__ __forceinline__ void jacobi_rotation(double p, double beta, double ga
 
 // Pointer into a lane's interleaved LDS arrays: consecutive elements of one
 // lane are ST words apart (ST = hypotheses per workgroup).
+// The pointer is typed as LDS: left generic, the compiler loses track of the address
+// space in the larger instantiations and falls back to flat loads, which cost several
+// times an LDS read.
+typedef __attribute__((address_space(3))) double lds_double;
 template <int ST> struct LP {
-    double *p;
-    __device__ double &operator[](int e) const { return p[e * ST]; }
-    __device__ double &operator*() const { return *p; }
+    lds_double *p;
+    __device__ lds_double &operator[](int e) const { return p[e * ST]; }
+    __device__ lds_double &operator*() const { return *p; }
     __device__ LP operator+(int e) const { return LP{p + e * ST}; }
     __device__ LP &operator+=(int e)
     {
@@ -399,7 +403,7 @@ template <int N> struct JacobiRow {
         w = norm2;
         dirty = false;
     }
-    template <int ST> __device__ __forceinline__ void store(LP<ST> row, double &norm2) const
+    template <int ST> __device__ __forceinline__ void store(LP<ST> row, lds_double &norm2) const
     {
         if (!dirty)
             return;
@@ -772,27 +776,6 @@ __device__ void jacobi_sweeps_12_shared(LP<ST> At, LP<ST> W, int g, int hl)
     }
 }
 
-// jacobi_svd_12 for a wave whose 64 lanes hold identical copies of the matrix (At, W in
-// each lane's own arrays): the sweeps run once on a compact copy in `sh`
-// (COOP_SH_DOUBLES doubles of LDS that no lane's arrays overlap), six lanes taking the
-// up to six independent pairs of a step.
-constexpr int COOP_SH_DOUBLES = 160;
-template <int ST> __device__ void jacobi_svd_12_coop(LP<ST> At, LP<ST> W, double *sh, int lane)
-{
-    jacobi_init_norms_12<ST>(At, W);
-    for (int e = lane; e < 144; e += 64)
-        sh[e] = At[e];
-    if (lane < 12)
-        sh[144 + lane] = W[lane];
-    wave_sync();
-    jacobi_sweeps_12_shared<1, 64, 1, true>(LP<1>{sh}, LP<1>{sh + 144}, lane, 0);
-    for (int e = 0; e < 144; e++)
-        At[e] = sh[e];
-    for (int e = 0; e < 12; e++)
-        W[e] = sh[144 + e];
-    jacobi_finish_12<ST>(At, W);
-}
-
 // A lane's LDS arrays (offsets in doubles; LDS_DOUBLES per hypothesis).  Lifetimes
 // overlap so that the peak is the 12 x 12 matrix plus its 12 row norms:
 //   ut  12 x 12: MtM, then its left singular vectors (rows), with w = the row norms.
@@ -811,10 +794,14 @@ constexpr int OFF_SW = 115;  // 5
 constexpr int OFF_V = 120;   // 36: rows 8, 9, 10 of ut
 constexpr int OFF_W = 144;   // 12
 constexpr int LDS_DOUBLES = 156; // 32 hypotheses = 39 KiB: four workgroups per CU
+// Element stride of a solve workgroup with fewer hypotheses than this (part of its LDS is
+// then unused): 4096 hypotheses at 8 per wave take 0.26 ms with stride 32 and 0.28 ms
+// with stride 8 (the Gauss-Newton step, the most LDS-bound one, is 1.5 times slower).
+constexpr int LDS_MIN_STRIDE = 32;
 
 template <int ST> struct EpnpLds {
     LP<ST> ut, w, sa, sv, sw, l, ga, v;
-    __device__ explicit EpnpLds(double *lane_base)
+    __device__ explicit EpnpLds(lds_double *lane_base)
         : ut{lane_base + OFF_UT * ST}, w{lane_base + OFF_W * ST}, sa{lane_base + OFF_SA * ST},
           sv{lane_base + OFF_SV * ST}, sw{lane_base + OFF_SW * ST}, l{lane_base + OFF_L * ST},
           ga{lane_base + OFF_GA * ST}, v{lane_base + OFF_V * ST}
@@ -1349,24 +1336,29 @@ __device__ double compute_R_and_t(const Points &P, EpnpState &e, const EpnpLds<S
     return sum2 / n;
 }
 
-// How the lanes of a wave share the 12 x 12 decomposition inside epnp_pose.
+// How the lanes of a wave are used by epnp_pose.
 enum PoseMode {
     POSE_LANE,    // every lane solves its own problem by itself
     POSE_HELPED,  // lanes ST*g + hl, g = 0..64/ST-1, serve problem hl: all of them run the
                   // solve (same instructions, same LDS copy, identical values) and split
                   // the independent Jacobi pairs and the independent candidates
-    POSE_WAVE     // all 64 lanes run the same solve on identical private copies (refit)
+    POSE_WAVE     // ST == 1: the 64 lanes serve one problem as in POSE_HELPED, but the sums
+                  // over the points are split over the lanes (Points::step == 64), so the
+                  // candidates, whose pose step has such sums, run one after the other
 };
 
 // epnp::compute_pose on the correspondences P.  Returns true in the lane that reports
-// the result (one per problem).  lane / sh: see the modes (sh = the compact LDS
-// area of jacobi_svd_12_coop, POSE_WAVE only).
-template <int ST, PoseMode MODE = POSE_LANE>
-__device__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3], double t[3],
-                          int lane = 0, double *sh = nullptr)
+// the result (one per problem).
+// HPW = problems per wave in the grouped modes (the lane stride between the members of
+// a group); the LDS element stride ST may be larger.
+template <int ST, PoseMode MODE = POSE_LANE, int HPW = ST>
+__device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3], double t[3],
+                          int lane = 0)
 {
     EpnpState e;
-    const int member = MODE == POSE_HELPED ? lane / ST : 0;
+    constexpr int G = MODE == POSE_LANE ? 1 : 64 / HPW;
+    const int member = MODE == POSE_LANE ? 0 : lane / HPW;
+    const LaneGroup grp = MODE == POSE_LANE ? LaneGroup() : LaneGroup{member, lane % HPW, HPW, G};
     PNP_STAMP(0);
     choose_control_points(P, e, S);
     PNP_STAMP(1);
@@ -1375,12 +1367,12 @@ __device__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3],
     accumulate_mtm(P, e, S);
     PNP_STAMP(3);
     // MtM is symmetric, so it is its own transposed copy; EPnP reads only U
-    if constexpr (MODE == POSE_WAVE) {
-        jacobi_svd_12_coop<ST>(S.ut, S.w, sh, lane);
-    } else if constexpr (MODE == POSE_HELPED) {
+    if constexpr (MODE != POSE_LANE) {
         jacobi_init_norms_12<ST>(S.ut, S.w);
         wave_sync();
-        jacobi_sweeps_12_shared<ST, 64 / ST, ST, false>(S.ut, S.w, member, lane % ST);
+        // six or more lanes per matrix take every pair of a step at once: then
+        // overlapping the sweeps pays (12 rounds per sweep instead of 21)
+        jacobi_sweeps_12_shared<ST, G, HPW, G >= 6>(S.ut, S.w, member, lane % HPW);
         jacobi_finish_12<ST>(S.ut, S.w);
     } else {
         jacobi_svd_12<ST>(S.ut, S.w);
@@ -1403,9 +1395,7 @@ __device__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3],
         // for each: the members of a group take different candidates at once.  L stays
         // where it is while Gauss-Newton runs, so two 6 x 4 matrices fit beside it;
         // the pose step needs 21 doubles per candidate and L is dead by then.
-        constexpr int G = 64 / ST;
         double betas[3][4];
-        const LaneGroup grp{member, lane % ST, ST, G};
         find_betas_approx(1, S, rho, betas[0], grp);
         PNP_STAMP(6);
         find_betas_approx(2, S, rho, betas[1], grp);
@@ -1423,7 +1413,7 @@ __device__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3],
             gauss_newton(Sm, rho, b);
             // every member needs every candidate's betas for the pose step
             for (int k = 0; k < 4; k++) {
-                const double other = __shfl_xor(b[k], ST, 64);
+                const double other = __shfl_xor(b[k], HPW, 64);
                 betas[0][k] = second ? other : b[k];
                 betas[1][k] = second ? b[k] : other;
             }
@@ -1474,7 +1464,7 @@ __device__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3],
     double best_err = 0;
     for (int c = 1; c <= 3; c++) {
         double betas[4], Rc[3][3], tc[3];
-        find_betas_approx(c, S, rho, betas);
+        find_betas_approx(c, S, rho, betas, grp);
         PNP_STAMP(6 + 3 * (c - 1));
         gauss_newton(S, rho, betas);
         PNP_STAMP(7 + 3 * (c - 1));
@@ -1607,7 +1597,7 @@ __device__ inline Points make_points(const float *obj, const float *img, const i
 // Solve kernel: lane l < HPW of workgroup b solves hypothesis h = b*HPW + l (EPnP
 // on rows subsets[5h .. 5h+5)) and writes its model (rvec, tvec) to models[6h..]; the
 // lanes l + HPW, l + 2*HPW, ... of the wave join it for the Jacobi sweeps (POSE_HELPED).
-// Dynamic LDS: HPW * LDS_DOUBLES doubles.
+// Dynamic LDS: max(HPW, LDS_MIN_STRIDE) * LDS_DOUBLES doubles.
 // A batch holds n_problems independent problems of hyp_per_problem hypotheses
 // each; problem p owns the correspondence rows [begins[p], ends[p]) (begins ==
 // nullptr: one problem over all rows) and its subsets index rows of that range.
@@ -1624,11 +1614,12 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(const float *__restric
     const int h = h0 + blockIdx.x * HPW + hl;
     if (h >= n_hyp)
         return;
-    const EpnpLds<HPW> S(lds + hl);
+    constexpr int ST = HPW < LDS_MIN_STRIDE ? LDS_MIN_STRIDE : HPW;
+    const EpnpLds<ST> S((lds_double *)lds + hl);
     const int64_t row0 = begins ? begins[h / hyp_per_problem] : 0;
     const Points P = make_points(obj + 3 * row0, img + 2 * row0, subsets + (int64_t)h * 5, 5, K);
     double R[3][3], t[3], r[3];
-    if (!epnp_pose<HPW, HPW < 64 ? POSE_HELPED : POSE_LANE>(P, S, R, t, lane))
+    if (!epnp_pose<ST, HPW < 64 ? POSE_HELPED : POSE_LANE, HPW>(P, S, R, t, lane))
         return;
     rodrigues_mat_to_vec(S, R, r);
     PNP_STAMP(15);
@@ -1689,10 +1680,10 @@ __global__ __launch_bounds__(256) void inlier_mask_kernel(const float *__restric
 }
 
 // solvePnP(SOLVEPNP_EPNP) on rows idx[0..n) (idx may be null): model[6] = rvec|tvec.
-// One wave, one problem: every lane runs the whole solve on its own LDS copy
-// (the 64-hypothesis layout), but the sums over the n points are split over the
-// lanes and combined with wave_sum(), so a refit on thousands of inliers costs
-// little more than a 5-point solve.  (The split changes the order of those sums:
+// One wave, one problem: every lane runs the whole solve on the one LDS copy (all lanes
+// write the same values), the independent Jacobi pairs of a step go to different lanes,
+// and the sums over the n points are split over the lanes and combined with wave_sum(),
+// so a refit on thousands of inliers costs less than a 5-point solve of one lane.  (The split changes the order of those sums:
 // the result differs from a sequential statement by rounding, ~1e-13 relative.)
 // n < 64 runs the sequential order on every lane instead.
 __global__ __launch_bounds__(64) void epnp_solve_kernel(const float *__restrict__ obj,
@@ -1702,14 +1693,14 @@ __global__ __launch_bounds__(64) void epnp_solve_kernel(const float *__restrict_
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    const EpnpLds<64> S(lds + lane);
+    const EpnpLds<1> S((lds_double *)lds);
     Points P = make_points(obj, img, idx, n, K);
     if (n >= 64) {
         P.first = lane;
         P.step = 64;
     }
     double R[3][3], t[3], r[3];
-    epnp_pose<64, POSE_WAVE>(P, S, R, t, lane, lds + 64 * LDS_DOUBLES);
+    epnp_pose<1, POSE_WAVE>(P, S, R, t, lane);
     rodrigues_mat_to_vec(S, R, r);
     if (lane == 0) {
         model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
@@ -1749,7 +1740,7 @@ __global__ __launch_bounds__(64) void epnp_solve_batched_kernel(
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
-    const EpnpLds<64> S(lds + lane);
+    const EpnpLds<1> S((lds_double *)lds);
     const int64_t row0 = row_begins[b];
     const int n = idx_counts[b];
     Points P = make_points(obj + 3 * row0, img + 2 * row0, idx + idx_begins[b], n, K);
@@ -1758,7 +1749,7 @@ __global__ __launch_bounds__(64) void epnp_solve_batched_kernel(
         P.step = 64;
     }
     double R[3][3], t[3], r[3];
-    epnp_pose<64, POSE_WAVE>(P, S, R, t, lane, lds + 64 * LDS_DOUBLES);
+    epnp_pose<1, POSE_WAVE>(P, S, R, t, lane);
     rodrigues_mat_to_vec(S, R, r);
     if (lane == 0) {
         double *model = models + (int64_t)b * 6;
@@ -1773,7 +1764,8 @@ static hipError_t launch_solve(const float *d_obj, const float *d_img, CameraK K
                                int hyp_per_problem, int h0, int n_hyp, double *d_models,
                                hipStream_t stream)
 {
-    const size_t lds_bytes = (size_t)HPW * LDS_DOUBLES * sizeof(double);
+    const size_t lds_bytes =
+        (size_t)(HPW < LDS_MIN_STRIDE ? LDS_MIN_STRIDE : HPW) * LDS_DOUBLES * sizeof(double);
     // opt in to > 64 KiB of dynamic LDS (per device, so not cached across calls)
     hipError_t e = hipFuncSetAttribute((const void *)ransac_solve_kernel<HPW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1798,8 +1790,11 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     const int n_hyp = (int)total;
     // Hypotheses per wave: one wave's fp64 instruction stream keeps its SIMD busy, and
     // LDS capacity (1248 B per hypothesis -> 128 per CU) sets how many hypotheses are
-    // in flight, so few hypotheses go 16 to a wave (as many CUs and SIMDs as
-    // possible) and many go 32 to a wave (4 workgroups per CU, one per SIMD).
+    // in flight, so many hypotheses go 32 to a wave (4 workgroups per CU, one per SIMD,
+    // two lanes per hypothesis).  Fewer go 16 or 8 to a wave: more lanes per hypothesis
+    // shorten its solve (8 lanes take all the independent Jacobi pairs of a step and
+    // all three candidates at once) while the waves still fit the SIMDs in one round.
+    const bool tiny = n_hyp <= n_cus * 4 * 8;
     const bool small = n_hyp <= n_cus * 4 * 16;
     // A large batch goes down in rounds of one GPU-full of solves; the scoring of a
     // round runs on a second stream underneath the next round's solves (the solve
@@ -1809,7 +1804,10 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     hipError_t e;
     for (int h0 = 0; h0 < n_hyp; h0 += split ? round : n_hyp) {
         const int h1 = split ? (n_hyp - h0 > round ? h0 + round : n_hyp) : n_hyp;
-        if (small)
+        if (tiny)
+            e = launch_solve<8>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
+                                d_models, stream);
+        else if (small)
             e = launch_solve<16>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
                                  d_models, stream);
         else
@@ -1855,7 +1853,7 @@ hipError_t inlier_mask_launch(const float *d_obj, const float *d_img, int n, Cam
 hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,
                              CameraK K, double *d_model, hipStream_t stream)
 {
-    const size_t lds_bytes = ((size_t)64 * LDS_DOUBLES + COOP_SH_DOUBLES) * sizeof(double);
+    const size_t lds_bytes = (size_t)LDS_DOUBLES * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void *)epnp_solve_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
@@ -1887,7 +1885,7 @@ hipError_t epnp_solve_batched_launch(const float *d_obj, const float *d_img,
 {
     if (n_problems <= 0)
         return hipSuccess;
-    const size_t lds_bytes = ((size_t)64 * LDS_DOUBLES + COOP_SH_DOUBLES) * sizeof(double);
+    const size_t lds_bytes = (size_t)LDS_DOUBLES * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void *)epnp_solve_batched_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)

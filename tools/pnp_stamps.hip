@@ -10,6 +10,17 @@ __device__ long long g_pnp_stamps[32];
 #include "../poseestimation_amd/csrc/ransac_epnp.hip"
 using namespace posehip;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
+static int print_hyp_stamps()
+{
+    long long st[32];
+    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pnp_stamps), sizeof(st)) != hipSuccess) return 1;
+    // hypothesis kernels: the candidates' Gauss-Newton and pose steps run side by side in the lanes of a group
+    const char *names[] = {"", "control points", "basis inverse", "MtM", "jacobi 12x12", "L_6x10", "betas1", "betas2", "betas3", "gn 1|2", "gn 3", "Rt round 1", "Rt round 2", "-", "-", "rodrigues"};
+    for (int k = 1; k <= 15; k++) if (st[k] == 0) st[k] = st[k - 1]; // stamps this mode does not write
+    for (int k = 1; k <= 15; k++) printf("%-16s %9lld cycles\n", names[k], st[k] - st[k - 1]);
+    printf("total            %9lld cycles\n", st[15] - st[0]);
+    return 0;
+}
 int main(int argc, char **argv)
 {
     const int n = 2000, H = argc > 1 ? atoi(argv[1]) : 4096;
@@ -93,7 +104,7 @@ int main(int argc, char **argv)
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf("H=%d HPW=%d solve only: %.3f ms -> %.3g hyps/s\n", H, hpw, ms, H / (ms * 1e-3));
         }
-        return 0;
+        return print_hyp_stamps();
     }
     for (int r = 0; r < 3; r++) {
         CK(hipEventRecord(e0));
@@ -102,13 +113,7 @@ int main(int argc, char **argv)
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("H=%d: %.3f ms -> %.3g hyps/s\n", H, ms, H / (ms * 1e-3));
     }
-    long long st[32];
-    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pnp_stamps), sizeof(st)));
-    // hypothesis kernels: the candidates' Gauss-Newton and pose steps run side by side in the lanes of a group
-    const char *names[] = {"", "control points", "basis inverse", "MtM", "jacobi 12x12", "L_6x10", "betas1", "betas2", "betas3", "gn 1|2", "gn 3", "Rt round 1", "Rt round 2", "-", "-", "rodrigues"};
-    for (int k = 1; k <= 15; k++) if (st[k] == 0) st[k] = st[k - 1]; // stamps this mode does not write
-    for (int k = 1; k <= 15; k++) printf("%-16s %9lld cycles\n", names[k], st[k] - st[k - 1]);
-    printf("total            %9lld cycles\n", st[15] - st[0]);
+    if (print_hyp_stamps()) return 1;
     std::vector<int32_t> c(H); CK(hipMemcpy(c.data(), d_counts, H * 4, hipMemcpyDeviceToHost));
     int mx = 0; for (int v : c) mx = v > mx ? v : mx;
     printf("max count %d\n", mx);
