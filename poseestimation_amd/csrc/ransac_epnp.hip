@@ -8,18 +8,21 @@
 // pose from the best one), converts R to a rotation vector, and counts the
 // points whose float squared reprojection error is <= threshold^2.
 //
-// Mapping.  The EPnP solve is a strictly sequential fp64 computation whose
-// critical path (Jacobi rotation angles: sqrt, divide, hypot per row pair) cannot
-// be spread over lanes without changing the rounding, so the solve kernel runs
-// ONE HYPOTHESIS PER LANE: every instruction of that chain serves up to 64
-// hypotheses.  Each lane keeps its small matrices (12 x 12 null-space problem,
-// 6 x 10 system, ...) in LDS, interleaved over the lanes (element e of lane l at
-// word e*HPW + l, so a wave access is conflict-free), 1248 bytes per hypothesis.
-// Every operation is in the order of a plain sequential statement of the
-// algorithm (built with -ffp-contract=off) so that poses agree with a CPU
-// statement to the last bits.  Per-point quantities (barycentric coordinates,
-// camera-frame points) are recomputed where they are used instead of stored, so
-// the same routine refits on any number of inliers in O(1) memory.
+// Mapping.  The EPnP solve is a sequential fp64 computation: every operation is in
+// the order of a plain sequential statement of the algorithm (built with
+// -ffp-contract=off) so that poses agree with a CPU statement to the last bits.
+// A hypothesis keeps its small matrices (12 x 12 null-space problem, 6 x 10
+// system, ...) in LDS, interleaved over the hypotheses of a wave (element e of
+// hypothesis h at word e*HPW + h, so a wave access is conflict-free), 1248 bytes
+// per hypothesis: LDS holds 128 hypotheses per CU, i.e. 32 or fewer per wave, so
+// a hypothesis is served by a GROUP OF 2..8 LANES.  The lanes of a group run the
+// same instructions on the same LDS copy and split the work the sequential order
+// leaves independent - the Jacobi pairs (i, j) with equal i + j, which touch
+// different rows, and the three candidates' Gauss-Newton and pose steps - each
+// piece with the operations and operands it has in the sequential order.
+// Per-point quantities (barycentric coordinates, camera-frame points) are
+// recomputed where they are used instead of stored, so the same routine refits
+// on any number of inliers in O(1) memory.
 // Scoring is a second kernel with ONE HYPOTHESIS PER WAVEFRONT: the 64 lanes
 // stride over the correspondences and the inlier count is reduced with
 // ballot + popcount.
