@@ -717,6 +717,23 @@ template <int ST> __device__ void jacobi_finish_12(LP<ST> At, LP<ST> W)
     }
 }
 
+// Rounds of one 12 x 12 sweep for 2 and 4 lanes per matrix: byte g of a word = the pair
+// (i << 4 | j) of member g, 0xFF = none.  A list schedule of the pair dependencies (pair
+// (i, j) needs the previous pairs on row i and on row j of the cyclic order: (i, j-1), or
+// (i-1, i) when j == i+1, and (i-1, j)), longest remaining chain first: 35 and 23 rounds,
+// against 39 and 26 when each step i + j - 1 = T is finished before the next begins.
+__device__ const uint32_t JACOBI_ROUNDS_2[35] = {
+    0xFFFFFF01u, 0xFFFFFF02u, 0xFFFF1203u, 0xFFFF1304u, 0xFFFF1405u, 0xFFFF0623u, 0xFFFF2415u,
+    0xFFFF1607u, 0xFFFF3425u, 0xFFFF1708u, 0xFFFF3526u, 0xFFFF1809u, 0xFFFF3627u, 0xFFFF0A45u,
+    0xFFFF2819u, 0xFFFF4637u, 0xFFFF1A0Bu, 0xFFFF3829u, 0xFFFF5647u, 0xFFFF2A1Bu, 0xFFFF4839u,
+    0xFFFF2B57u, 0xFFFF493Au, 0xFFFF6758u, 0xFFFF4A3Bu, 0xFFFF6859u, 0xFFFF5A4Bu, 0xFFFF7869u,
+    0xFFFF6A5Bu, 0xFFFF6B79u, 0xFFFF897Au, 0xFFFF8A7Bu, 0xFFFF9A8Bu, 0xFFFFFF9Bu, 0xFFFFFFABu};
+__device__ const uint32_t JACOBI_ROUNDS_4[23] = {
+    0xFFFFFF01u, 0xFFFFFF02u, 0xFFFF1203u, 0xFFFF1304u, 0xFF231405u, 0xFF241506u, 0x34251607u,
+    0x35261708u, 0x36271809u, 0x28190A45u, 0x1A0B4637u, 0x56473829u, 0x48392A1Bu, 0x493A2B57u,
+    0x4A3B6758u, 0xFF4B6859u, 0xFF78695Au, 0xFF796A5Bu, 0xFF897A6Bu, 0xFFFF8A7Bu, 0xFFFF9A8Bu,
+    0xFFFFFF9Bu, 0xFFFFFFABu};
+
 // The sweeps of jacobi_svd_12 with G lanes per matrix.  In the cyclic order pair (i, j)
 // depends only on the earlier pairs that touch row i or row j, which are (i, j - 1) and
 // (i - 1, j) and what precedes those; so all pairs with i + j - 1 == T can run once step
@@ -745,6 +762,22 @@ __device__ void jacobi_sweeps_12_shared(LP<ST> At, LP<ST> W, int g, int hl)
     unsigned long long group = 0;
     for (int m = 0; m < G; m++)
         group |= 1ull << (m * HPW);
+    if constexpr (G == 2 || G == 4) {
+        const uint32_t *rounds = G == 2 ? JACOBI_ROUNDS_2 : JACOBI_ROUNDS_4;
+        constexpr int N_ROUNDS = G == 2 ? 35 : 23;
+        for (int s = 0; s < MAX_SWEEPS; s++) {
+            bool rotated = false;
+            for (int r = 0; r < N_ROUNDS; r++) {
+                const uint32_t e = rounds[r] >> (8 * g) & 0xFF;
+                if (e != 0xFF)
+                    rotated |= jacobi_pair_lds<ST, N>(At, W, e >> 4, e & 15, eps);
+                wave_sync();
+            }
+            if ((__builtin_amdgcn_ballot_w64(rotated) >> hl & group) == 0)
+                return;
+        }
+        return;
+    }
     bool rot_old = false, rot_new = false; // a rotation in sweep s - 1 / in sweep s
     for (int s = 0; s <= MAX_SWEEPS; s++) {
         for (int T0 = 0; T0 < PERIOD; T0++) {

@@ -161,3 +161,61 @@ def test_scheduled_sweeps_equal_cyclic_sweeps_bitwise(shape, G, overlap):
         n1 = sweeps_scheduled(A1, G, overlap)
         assert n0 == n1
         assert A0.tobytes() == A1.tobytes()
+
+
+def table_rounds(name, G):
+    """The precomputed rounds for 2 and 4 lanes per matrix, read from the kernel source."""
+    import os
+    import re
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       "poseestimation_amd", "csrc", "ransac_epnp.hip")
+    text = open(src).read()
+    body = re.search(name + r"\[(\d+)\] = \{(.*?)\};", text, re.S)
+    words = [int(w.rstrip("u"), 16) for w in re.findall(r"0x[0-9A-Fa-f]+u", body.group(2))]
+    assert len(words) == int(body.group(1))
+    out = []
+    for w in words:
+        rnd = []
+        for g in range(4):
+            e = (w >> (8 * g)) & 0xFF
+            if e != 0xFF:
+                assert g < G  # lanes beyond the group never get a pair
+                rnd.append((0, e >> 4, e & 15))
+        out.append(rnd)
+    return out
+
+
+@pytest.mark.parametrize("name,G,n_rounds", [("JACOBI_ROUNDS_2", 2, 35), ("JACOBI_ROUNDS_4", 4, 23)])
+def test_precomputed_rounds_keep_every_rows_pair_sequence(name, G, n_rounds):
+    rs = table_rounds(name, G)
+    assert len(rs) == n_rounds
+    flat = [p for rnd in rs for p in rnd]
+    want = [(0, i, j) for (i, j) in cyclic(12)]
+    assert sorted(flat) == sorted(want)
+    for rnd in rs:
+        rows = [r for (_, i, j) in rnd for r in (i, j)]
+        assert len(rows) == len(set(rows)) and all(0 <= i < j < 12 for (_, i, j) in rnd)
+    assert row_sequences(flat, 12) == row_sequences(want, 12)
+
+
+@pytest.mark.parametrize("name,G", [("JACOBI_ROUNDS_2", 2), ("JACOBI_ROUNDS_4", 4)])
+def test_precomputed_rounds_equal_cyclic_sweeps_bitwise(name, G):
+    rs = table_rounds(name, G)
+    eps = np.finfo(np.float64).eps * 10
+    rng = np.random.default_rng(G)
+    for trial in range(4):
+        M = rng.standard_normal((12, 12))
+        if trial % 2:
+            M = M @ M.T
+        A0, A1 = M.copy(), M.copy()
+        n0 = sweeps_cyclic(A0)
+        W = np.array([float(np.dot(r, r)) for r in A1])
+        n1 = 0
+        for n1 in range(1, 31):
+            rotated = False
+            for rnd in rs:
+                for (_, i, j) in rnd:
+                    rotated |= pair(A1, W, i, j, eps)
+            if not rotated:
+                break
+        assert n0 == n1 and A0.tobytes() == A1.tobytes()
