@@ -1396,13 +1396,13 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
     PnpDev d;
     if ((s = upload_pnp(obj, img, n, subsets, (size_t)total, st, d)) != PH_OK)
         return s;
-    // pinned results, written by the kernels: models | counts | mask | refit model
+    // pinned results, written by the kernels: models | counts | refit model | inlier count |
+    // inlier list
     const int chunk = 4096, cmax = std::min(total, chunk);
     const size_t counts_off = align256((size_t)cmax * 6 * sizeof(double));
-    const size_t mask_off = counts_off + align256((size_t)cmax * sizeof(int32_t));
-    const size_t best_off = mask_off + align256((size_t)n);
-    const size_t refit_off = best_off + 256;
-    PH_HIP(g_ctx.h_out.reserve(refit_off + 256));
+    const size_t best_off = counts_off + align256((size_t)cmax * sizeof(int32_t));
+    const size_t refit_off = best_off, ninl_off = refit_off + 256, list_off = ninl_off + 256;
+    PH_HIP(g_ctx.h_out.reserve(list_off + (size_t)n * sizeof(int32_t)));
     uint8_t *hb = (uint8_t *)g_ctx.h_out.p, *db = (uint8_t *)g_ctx.h_out.dp;
     const double *models = (const double *)hb;
     const int32_t *counts = (const int32_t *)(hb + counts_off);
@@ -1429,40 +1429,27 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
         *found = 0;
         return PH_OK;
     }
-    // inlier mask of the best model, then one EPnP solve over its inliers
-    memcpy(hb + best_off, best, sizeof(best)); // the device reads the model from pinned memory
-    PH_HIP(inlier_mask_launch(d.obj, d.img, n, cam, (const double *)(db + best_off), thr2,
-                              db + mask_off, st));
+    // inliers of the best model and one EPnP solve over them, in one launch
+    RefitOne one;
+    memcpy(one.best, best, sizeof(best));
+    one.rows = n;
+    PH_HIP(g_ctx.pnp_idx.reserve((size_t)n * sizeof(int32_t)));
+    PH_HIP(epnp_refit_batched_launch(d.obj, d.img, nullptr, nullptr, nullptr, nullptr, one, 1, cam,
+                                     thr2, (int32_t *)g_ctx.pnp_idx.p, (int32_t *)(db + list_off),
+                                     (int32_t *)(db + ninl_off), (double *)(db + refit_off), st));
     PH_HIP(hipStreamSynchronize(st));
-    const uint8_t *mask = hb + mask_off;
-    std::vector<int32_t> idx;
-    idx.reserve((size_t)max_good);
-    for (int i = 0; i < n; i++)
-        if (mask[i])
-            idx.push_back(i);
-    const int k = (int)idx.size();
+    const int k = *(const int32_t *)(hb + ninl_off);
     if (k < 4) { // cannot happen with max_good >= 5; solvePnP would throw and RANSAC report failure
         memcpy(rvec, best, 3 * sizeof(double));
         memcpy(tvec, best + 3, 3 * sizeof(double));
         *found = 0;
         return PH_OK;
     }
-    // the subset table is no longer needed: the inlier list goes through the same
-    // pinned area (behind obj | img) and one copy
-    PH_HIP(g_ctx.pnp_idx.reserve((size_t)k * sizeof(int32_t)));
-    const size_t idx_off = align256((size_t)n * 12) + align256((size_t)n * 8);
-    PH_HIP(g_ctx.h_in.reserve(idx_off + (size_t)k * sizeof(int32_t)));
-    memcpy((uint8_t *)g_ctx.h_in.p + idx_off, idx.data(), (size_t)k * sizeof(int32_t));
-    PH_HIP(hipMemcpyAsync(g_ctx.pnp_idx.p, (uint8_t *)g_ctx.h_in.p + idx_off,
-                          (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    PH_HIP(epnp_solve_launch(d.obj, d.img, (const int32_t *)g_ctx.pnp_idx.p, k, cam,
-                             (double *)(db + refit_off), st));
-    PH_HIP(hipStreamSynchronize(st));
     const double *m6 = (const double *)(hb + refit_off);
     memcpy(rvec, m6, 3 * sizeof(double));
     memcpy(tvec, m6 + 3, 3 * sizeof(double));
     if (inliers)
-        memcpy(inliers, idx.data(), (size_t)k * sizeof(int32_t));
+        memcpy(inliers, hb + list_off, (size_t)k * sizeof(int32_t));
     if (n_inliers)
         *n_inliers = k;
     *found = 1;
@@ -1535,12 +1522,10 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
     const size_t rows = (size_t)row_hi;
     const size_t img_off = align256(rows * 12), tab_off = img_off + align256(rows * 8);
     const size_t np4 = align256((size_t)n_problems * sizeof(int32_t));
-    const size_t beg_off = tab_off, end_off = beg_off + np4, rowb_off = end_off + np4;
-    const size_t ibeg_off = rowb_off + np4, icnt_off = ibeg_off + np4;
-    const size_t best_off = icnt_off + np4;
+    const size_t beg_off = tab_off, end_off = beg_off + np4, all_off = end_off + np4;
+    const size_t best_off = all_off + np4;
     const size_t sub_off = best_off + align256((size_t)n_problems * 6 * sizeof(double));
-    const size_t idx_off = sub_off + align256(cap_hyps * 5 * sizeof(int32_t));
-    const size_t in_total = idx_off + align256(rows * sizeof(int32_t));
+    const size_t in_total = sub_off + align256(cap_hyps * 5 * sizeof(int32_t));
     PH_HIP(g_ctx.h_in.reserve(in_total));
     PH_HIP(g_ctx.d_in.reserve(tab_off));
     uint8_t *hi = (uint8_t *)g_ctx.h_in.p, *di = (uint8_t *)g_ctx.h_in.dp;
@@ -1549,10 +1534,12 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
     PH_HIP(hipMemcpyAsync(g_ctx.d_in.p, hi, tab_off, hipMemcpyHostToDevice, st));
     const float *d_obj = (const float *)g_ctx.d_in.p;
     const float *d_img = (const float *)((const uint8_t *)g_ctx.d_in.p + img_off);
-    // pinned result area, written by the kernels: models | counts | mask | refit models
+    // pinned result area, written by the kernels: models | counts | inlier lists (one slot
+    // per row) | inlier counts | refit models
     const size_t cnt_off = align256(cap_hyps * 6 * sizeof(double));
-    const size_t mask_off = cnt_off + align256(cap_hyps * sizeof(int32_t));
-    const size_t refit_off = mask_off + align256(rows);
+    const size_t list_off = cnt_off + align256(cap_hyps * sizeof(int32_t));
+    const size_t ninl_off = list_off + align256(rows * sizeof(int32_t));
+    const size_t refit_off = ninl_off + np4;
     PH_HIP(g_ctx.h_out.reserve(refit_off + (size_t)n_problems * 6 * sizeof(double)));
     uint8_t *ho = (uint8_t *)g_ctx.h_out.p, *dout = (uint8_t *)g_ctx.h_out.dp;
     const double *models = (const double *)ho;
@@ -1609,81 +1596,50 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
         }
     }
 
-    // problems with a model: inlier masks of the best models in one launch
-    std::vector<int> cand;
-    int cand_max_n = 0;
+    // the final step in one launch: problems with a model list its inliers and refit on
+    // them, problems of exactly five rows solve on all their rows
+    std::vector<int> refit;
     double *h_best = (double *)(hi + best_off);
+    uint8_t *h_all = hi + all_off;
     for (int p = 0; p < n_problems; p++) {
         if (iterations_run)
             iterations_run[p] = pr[p].iter;
-        if (pr[p].live && pr[p].max_good > 0) {
-            const int c = (int)cand.size();
-            h_beg[c] = point_offsets[p];
-            h_end[c] = point_offsets[p + 1];
-            memcpy(h_best + (size_t)c * 6, pr[p].best, sizeof(pr[p].best));
-            cand_max_n = std::max(cand_max_n, pr[p].n);
-            cand.push_back(p);
-        }
-    }
-    if (!cand.empty()) {
-        PH_HIP(inlier_mask_batched_launch(d_obj, d_img, (const int32_t *)(di + beg_off),
-                                          (const int32_t *)(di + end_off), (int)cand.size(),
-                                          cand_max_n, cam, (const double *)(di + best_off), thr2,
-                                          dout + mask_off, st));
-        PH_HIP(hipStreamSynchronize(st));
-    }
-    // refit list: the candidates' inliers, and every row of the five-point problems
-    const uint8_t *mask = ho + mask_off;
-    int32_t *h_rowb = (int32_t *)(hi + rowb_off), *h_ibeg = (int32_t *)(hi + ibeg_off);
-    int32_t *h_icnt = (int32_t *)(hi + icnt_off), *h_idx = (int32_t *)(hi + idx_off);
-    std::vector<int> refit;
-    size_t n_idx = 0;
-    size_t ci = 0;
-    for (int p = 0; p < n_problems; p++) {
-        const bool is_cand = ci < cand.size() && cand[ci] == p;
-        if (is_cand)
-            ci++;
-        if (!is_cand && pr[p].n != model_points)
+        const bool has_model = pr[p].live && pr[p].max_good > 0;
+        if (!has_model && pr[p].n != model_points)
             continue;
-        const int r0 = point_offsets[p];
-        const size_t first = n_idx;
-        for (int i = 0; i < pr[p].n; i++)
-            if (!is_cand || mask[(size_t)r0 + i])
-                h_idx[n_idx++] = i;
-        const int k = (int)(n_idx - first);
-        if (k < 4) { // cannot happen with a model of >= 5 inliers
-            n_idx = first;
-            continue;
-        }
         const int b = (int)refit.size();
-        h_rowb[b] = r0;
-        h_ibeg[b] = (int32_t)first;
-        h_icnt[b] = k;
+        h_beg[b] = point_offsets[p];
+        h_end[b] = point_offsets[p + 1];
+        h_all[b] = has_model ? 0 : 1;
+        memcpy(h_best + (size_t)b * 6, pr[p].best, sizeof(pr[p].best));
         refit.push_back(p);
     }
     if (refit.empty())
         return PH_OK;
-    PH_HIP(g_ctx.pnp_idx.reserve(n_idx * sizeof(int32_t)));
-    PH_HIP(hipMemcpyAsync(g_ctx.pnp_idx.p, h_idx, n_idx * sizeof(int32_t), hipMemcpyHostToDevice,
-                          st));
-    PH_HIP(epnp_solve_batched_launch(d_obj, d_img, (const int32_t *)(di + rowb_off),
-                                     (const int32_t *)g_ctx.pnp_idx.p,
-                                     (const int32_t *)(di + ibeg_off),
-                                     (const int32_t *)(di + icnt_off), (int)refit.size(), cam,
+    PH_HIP(g_ctx.pnp_idx.reserve(rows * sizeof(int32_t)));
+    PH_HIP(epnp_refit_batched_launch(d_obj, d_img, (const int32_t *)(di + beg_off),
+                                     (const int32_t *)(di + end_off),
+                                     (const double *)(di + best_off), di + all_off, RefitOne{},
+                                     (int)refit.size(), cam, thr2, (int32_t *)g_ctx.pnp_idx.p,
+                                     (int32_t *)(dout + list_off), (int32_t *)(dout + ninl_off),
                                      (double *)(dout + refit_off), st));
     PH_HIP(hipStreamSynchronize(st));
     const double *rm = (const double *)(ho + refit_off);
+    const int32_t *lists = (const int32_t *)(ho + list_off), *ninl = (const int32_t *)(ho + ninl_off);
     for (size_t b = 0; b < refit.size(); b++) {
-        const int p = refit[b];
+        const int p = refit[b], k = ninl[b];
+        if (k < 4) // cannot happen with a model of >= 5 inliers
+            continue;
         memcpy(rvecs + (size_t)p * 3, rm + b * 6, 3 * sizeof(double));
         memcpy(tvecs + (size_t)p * 3, rm + b * 6 + 3, 3 * sizeof(double));
         if (inliers)
-            memcpy(inliers + point_offsets[p], h_idx + h_ibeg[b], (size_t)h_icnt[b] * sizeof(int32_t));
+            memcpy(inliers + point_offsets[p], lists + point_offsets[p], (size_t)k * sizeof(int32_t));
         if (n_inliers)
-            n_inliers[p] = h_icnt[b];
+            n_inliers[p] = k;
         found[p] = 1;
     }
     (void)row_lo;
+    (void)max_n;
     return PH_OK;
 }
 

@@ -26,28 +26,28 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
                                     float thr2, double *d_models, int32_t *d_counts, int n_cus,
                                     hipStream_t stream, const RansacOverlap *overlap = nullptr);
 
-// One byte per row: 1 iff the row is an inlier of d_model (rvec|tvec).
-hipError_t inlier_mask_launch(const float *d_obj, const float *d_img, int n, CameraK K,
-                              const double *d_model, float thr2, uint8_t *d_mask,
-                              hipStream_t stream);
-
 // EPnP on rows d_idx[0..n) (d_idx may be null: rows 0..n) -> d_model = rvec|tvec.
 hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,
                              CameraK K, double *d_model, hipStream_t stream);
 
-// The two steps above for a batch: problem p owns rows [d_begins[p], d_ends[p]) (at most
-// max_n of them) and the model d_models[6p..]; d_mask is indexed by row.
-hipError_t inlier_mask_batched_launch(const float *d_obj, const float *d_img,
-                                      const int32_t *d_begins, const int32_t *d_ends,
-                                      int n_problems, int max_n, CameraK K, const double *d_models,
-                                      float thr2, uint8_t *d_mask, hipStream_t stream);
-
-// Problem b refits on rows d_idx[d_idx_begins[b] .. + d_idx_counts[b]), relative to its first
-// row d_row_begins[b] -> d_models[6b..].
-hipError_t epnp_solve_batched_launch(const float *d_obj, const float *d_img,
-                                     const int32_t *d_row_begins, const int32_t *d_idx,
-                                     const int32_t *d_idx_begins, const int32_t *d_idx_counts,
-                                     int n_problems, CameraK K, double *d_models,
-                                     hipStream_t stream);
+// The end of solvePnPRansac for a batch in one launch (one wave per problem): problem b owns
+// rows [d_begins[b], d_ends[b]); its inliers under d_best_models[6b..] (every row where
+// d_use_all_rows[b] != 0) are listed in ascending order, relative to d_begins[b], at
+// d_idx + d_begins[b] (device scratch the kernel reads back; as many entries as rows overall)
+// and d_idx_out + d_begins[b]; d_n_inliers[b] = the count; EPnP on the listed rows ->
+// d_models_out[6b..] = rvec|tvec (untouched if fewer than 4 rows are listed).
+// d_begins == nullptr: one problem over rows 0..one.rows with the model one.best, both
+// passed by value (d_ends, d_best_models and d_use_all_rows are then unused).
+struct RefitOne {
+    double best[6];
+    int rows;
+};
+hipError_t epnp_refit_batched_launch(const float *d_obj, const float *d_img,
+                                     const int32_t *d_begins, const int32_t *d_ends,
+                                     const double *d_best_models, const uint8_t *d_use_all_rows,
+                                     const RefitOne &one, int n_problems, CameraK K, float thr2,
+                                     int32_t *d_idx,
+                                     int32_t *d_idx_out, int32_t *d_n_inliers,
+                                     double *d_models_out, hipStream_t stream);
 
 } // namespace posehip

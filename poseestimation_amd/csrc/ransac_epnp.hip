@@ -1700,21 +1700,6 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restri
         counts[h] = good;
 }
 
-// Inlier mask of one model (rvec|tvec in model[6]) over all n rows.
-__global__ __launch_bounds__(256) void inlier_mask_kernel(const float *__restrict__ obj,
-                                                          const float *__restrict__ img, int n,
-                                                          CameraK K,
-                                                          const double *__restrict__ model,
-                                                          float thr2, uint8_t *__restrict__ mask)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n)
-        return;
-    double r[3] = {model[0], model[1], model[2]}, t[3] = {model[3], model[4], model[5]}, R[9];
-    rodrigues_vec_to_mat(r, R);
-    mask[i] = is_inlier(obj, img, i, R, t, K.fx, K.fy, K.cx, K.cy, thr2) ? 1 : 0;
-}
-
 // solvePnP(SOLVEPNP_EPNP) on rows idx[0..n) (idx may be null): model[6] = rvec|tvec.
 // One wave, one problem: every lane runs the whole solve on the one LDS copy (all lanes
 // write the same values), the independent Jacobi pairs of a step go to different lanes,
@@ -1744,43 +1729,61 @@ __global__ __launch_bounds__(64) void epnp_solve_kernel(const float *__restrict_
     }
 }
 
-// Inlier masks of a batch: problem p = blockIdx.y owns rows [begins[p], ends[p]) and
-// the model models[6p..6p+6); mask is indexed by row like obj / img.
-__global__ __launch_bounds__(256) void inlier_mask_batched_kernel(
+// The end of solvePnPRansac for a batch, one wave per problem: the inliers of the problem's
+// best model (all rows where use_all_rows[b] != 0: a problem of exactly five rows has no
+// model) are listed in ascending row order, then EPnP is solved on them as in
+// epnp_solve_kernel.  Problem b owns rows [begins[b], ends[b]); its list (rows relative to
+// begins[b]) goes to idx_dev + begins[b], which the solve reads back, and to idx_out +
+// begins[b]; n_inliers[b] = its length; models_out[6b..] = rvec|tvec (left alone, like
+// idx_out, when fewer than 4 rows are listed, which a model with 5 or more inliers
+// cannot produce).  begins == nullptr: one problem, rows 0..one.rows, model one.best
+// (passed by value: a single call then reads no table).
+__global__ __launch_bounds__(64) void epnp_refit_batched_kernel(
     const float *__restrict__ obj, const float *__restrict__ img,
-    const int32_t *__restrict__ begins, const int32_t *__restrict__ ends, CameraK K,
-    const double *__restrict__ models, float thr2, uint8_t *__restrict__ mask)
-{
-    const int p = blockIdx.y;
-    const int64_t row0 = begins[p];
-    const int n = ends[p] - begins[p];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n)
-        return;
-    const double *model = models + (int64_t)p * 6;
-    double r[3] = {model[0], model[1], model[2]}, t[3] = {model[3], model[4], model[5]}, R[9];
-    rodrigues_vec_to_mat(r, R);
-    mask[row0 + i] = is_inlier(obj + 3 * row0, img + 2 * row0, i, R, t, K.fx, K.fy, K.cx, K.cy, thr2)
-                         ? 1 : 0;
-}
-
-// epnp_solve_kernel for a batch: workgroup (one wave) b refits problem b on the rows
-// idx[idx_begins[b] .. idx_begins[b] + idx_counts[b]), which are relative to the
-// problem's first row row_begins[b]; models[6b..] = rvec|tvec.
-__global__ __launch_bounds__(64) void epnp_solve_batched_kernel(
-    const float *__restrict__ obj, const float *__restrict__ img,
-    const int32_t *__restrict__ row_begins, const int32_t *__restrict__ idx,
-    const int32_t *__restrict__ idx_begins, const int32_t *__restrict__ idx_counts, CameraK K,
-    double *__restrict__ models)
+    const int32_t *__restrict__ begins, const int32_t *__restrict__ ends,
+    const double *__restrict__ best_models, const uint8_t *__restrict__ use_all_rows,
+    RefitOne one, CameraK K, float thr2, int32_t *idx_dev, int32_t *__restrict__ idx_out,
+    int32_t *__restrict__ n_inliers, double *__restrict__ models_out)
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
+    const int64_t row0 = begins ? begins[b] : 0;
+    const int rows = begins ? ends[b] - begins[b] : one.rows;
+    obj += 3 * row0;
+    img += 2 * row0;
+    int32_t *list = idx_dev + row0;
+    int k = 0;
+    {
+        const bool all = begins ? use_all_rows[b] != 0 : false;
+        double rv[3], tv[3];
+        for (int e = 0; e < 3; e++) {
+            rv[e] = begins ? best_models[(int64_t)b * 6 + e] : one.best[e];
+            tv[e] = begins ? best_models[(int64_t)b * 6 + 3 + e] : one.best[3 + e];
+        }
+        double Rm[9];
+        rodrigues_vec_to_mat(rv, Rm);
+        for (int base = 0; base < rows; base += 64) {
+            const int i = base + lane;
+            const bool f = i < rows &&
+                           (all || is_inlier(obj, img, i, Rm, tv, K.fx, K.fy, K.cx, K.cy, thr2));
+            const unsigned long long votes = __ballot(f);
+            if (f)
+                list[k + __builtin_popcountll(votes & ((1ull << lane) - 1))] = i;
+            k += __builtin_popcountll(votes);
+        }
+    }
+    if (lane == 0)
+        n_inliers[b] = k;
+    if (k < 4)
+        return;
+    // the list was written by other lanes of this wave: make it visible to every lane's loads
+    __threadfence();
+    for (int i = lane; i < k; i += 64)
+        idx_out[row0 + i] = list[i];
     const EpnpLds<1> S((lds_double *)lds);
-    const int64_t row0 = row_begins[b];
-    const int n = idx_counts[b];
-    Points P = make_points(obj + 3 * row0, img + 2 * row0, idx + idx_begins[b], n, K);
-    if (n >= 64) {
+    Points P = make_points(obj, img, list, k, K);
+    if (k >= 64) {
         P.first = lane;
         P.step = 64;
     }
@@ -1788,7 +1791,7 @@ __global__ __launch_bounds__(64) void epnp_solve_batched_kernel(
     epnp_pose<1, POSE_WAVE>(P, S, R, t, lane);
     rodrigues_mat_to_vec(S, R, r);
     if (lane == 0) {
-        double *model = models + (int64_t)b * 6;
+        double *model = models_out + (int64_t)b * 6;
         model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
         model[3] = t[0]; model[4] = t[1]; model[5] = t[2];
     }
@@ -1875,17 +1878,6 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     return hipSuccess;
 }
 
-hipError_t inlier_mask_launch(const float *d_obj, const float *d_img, int n, CameraK K,
-                              const double *d_model, float thr2, uint8_t *d_mask,
-                              hipStream_t stream)
-{
-    if (n <= 0)
-        return hipSuccess;
-    inlier_mask_kernel<<<(n + 255) / 256, 256, 0, stream>>>(d_obj, d_img, n, K, d_model, thr2,
-                                                            d_mask);
-    return hipGetLastError();
-}
-
 hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,
                              CameraK K, double *d_model, hipStream_t stream)
 {
@@ -1898,36 +1890,20 @@ hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32
     return hipGetLastError();
 }
 
-hipError_t inlier_mask_batched_launch(const float *d_obj, const float *d_img,
-                                      const int32_t *d_begins, const int32_t *d_ends,
-                                      int n_problems, int max_n, CameraK K, const double *d_models,
-                                      float thr2, uint8_t *d_mask, hipStream_t stream)
-{
-    if (n_problems <= 0 || max_n <= 0)
-        return hipSuccess;
-    if (n_problems > 65535)
-        return hipErrorInvalidValue;
-    inlier_mask_batched_kernel<<<dim3((unsigned)((max_n + 255) / 256), (unsigned)n_problems), 256, 0,
-                                 stream>>>(d_obj, d_img, d_begins, d_ends, K, d_models, thr2,
-                                           d_mask);
-    return hipGetLastError();
-}
-
-hipError_t epnp_solve_batched_launch(const float *d_obj, const float *d_img,
-                                     const int32_t *d_row_begins, const int32_t *d_idx,
-                                     const int32_t *d_idx_begins, const int32_t *d_idx_counts,
-                                     int n_problems, CameraK K, double *d_models,
-                                     hipStream_t stream)
+hipError_t epnp_refit_batched_launch(const float *d_obj, const float *d_img,
+                                     const int32_t *d_begins, const int32_t *d_ends,
+                                     const double *d_best_models, const uint8_t *d_use_all_rows,
+                                     const RefitOne &one, int n_problems, CameraK K, float thr2,
+                                     int32_t *d_idx,
+                                     int32_t *d_idx_out, int32_t *d_n_inliers,
+                                     double *d_models_out, hipStream_t stream)
 {
     if (n_problems <= 0)
         return hipSuccess;
     const size_t lds_bytes = (size_t)LDS_DOUBLES * sizeof(double);
-    hipError_t e = hipFuncSetAttribute((const void *)epnp_solve_batched_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess)
-        return e;
-    epnp_solve_batched_kernel<<<n_problems, 64, lds_bytes, stream>>>(
-        d_obj, d_img, d_row_begins, d_idx, d_idx_begins, d_idx_counts, K, d_models);
+    epnp_refit_batched_kernel<<<n_problems, 64, lds_bytes, stream>>>(
+        d_obj, d_img, d_begins, d_ends, d_best_models, d_use_all_rows, one, K, thr2, d_idx,
+        d_idx_out, d_n_inliers, d_models_out);
     return hipGetLastError();
 }
 
