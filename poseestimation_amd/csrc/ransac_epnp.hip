@@ -1387,9 +1387,11 @@ enum PoseMode {
 // the result (one per problem).
 // HPW = problems per wave in the grouped modes (the lane stride between the members of
 // a group); the LDS element stride ST may be larger.
+// only = 1..3 (POSE_LANE / POSE_WAVE): run that candidate alone and report its R, t and
+// reprojection error *err_out; the caller applies the selection rule over the three.
 template <int ST, PoseMode MODE = POSE_LANE, int HPW = ST>
 __device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3], double t[3],
-                          int lane = 0)
+                          int lane = 0, int only = 0, double *err_out = nullptr)
 {
     EpnpState e;
     constexpr int G = MODE == POSE_LANE ? 1 : 64 / HPW;
@@ -1499,6 +1501,8 @@ __device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S,
     }
     double best_err = 0;
     for (int c = 1; c <= 3; c++) {
+        if (only != 0 && c != only)
+            continue;
         double betas[4], Rc[3][3], tc[3];
         find_betas_approx(c, S, rho, betas, grp);
         PNP_STAMP(6 + 3 * (c - 1));
@@ -1507,7 +1511,7 @@ __device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S,
         const double err = compute_R_and_t(P, e, S, N, betas, Rc, tc);
         PNP_STAMP(8 + 3 * (c - 1));
         // N = 1; if (err2 < err1) N = 2; if (err3 < err[N]) N = 3
-        if (c == 1 || err < best_err) {
+        if (c == 1 || only != 0 || err < best_err) {
             best_err = err;
             for (int i = 0; i < 3; i++) {
                 for (int j = 0; j < 3; j++)
@@ -1516,6 +1520,8 @@ __device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S,
             }
         }
     }
+    if (err_out)
+        *err_out = best_err;
     return true;
 }
 
@@ -1700,45 +1706,90 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restri
         counts[h] = good;
 }
 
-// solvePnP(SOLVEPNP_EPNP) on rows idx[0..n) (idx may be null): model[6] = rvec|tvec.
-// One wave, one problem: every lane runs the whole solve on the one LDS copy (all lanes
-// write the same values), the independent Jacobi pairs of a step go to different lanes,
-// and the sums over the n points are split over the lanes and combined with wave_sum(),
-// so a refit on thousands of inliers costs less than a 5-point solve of one lane.  (The split changes the order of those sums:
-// the result differs from a sequential statement by rounding, ~1e-13 relative.)
-// n < 64 runs the sequential order on every lane instead.
-__global__ __launch_bounds__(64) void epnp_solve_kernel(const float *__restrict__ obj,
-                                                        const float *__restrict__ img,
-                                                        const int32_t *__restrict__ idx, int n,
-                                                        CameraK K, double *__restrict__ model)
+// EPnP on the correspondences P by a workgroup of THREE waves, one per candidate (beta
+// initialisation): the candidates are independent chains after the null-space step, and a
+// lone wave is bound by the latency of its own instruction stream, so the three chains run
+// on three SIMDs at once instead of one after the other.  Each wave works on its own LDS
+// copy (lds + wave * LDS_DOUBLES) and repeats the common part (control points, MtM, the
+// 12 x 12 decomposition, L) for itself, which costs no time; every lane of a wave runs the
+// whole solve on the wave's copy (all lanes write the same values), the independent Jacobi
+// pairs of a step go to different lanes, and the sums over the points are split over the
+// lanes and combined with wave_sum() when P.n >= 64 (the split changes the order of those
+// sums: the result differs from a sequential statement by rounding, ~1e-13 relative;
+// fewer points run the sequential order on every lane).  The candidates' errors and poses
+// meet in LDS behind the three copies (3 x 13 doubles), and wave 0 applies OpenCV's
+// selection rule.  Returns true in wave 0, whose lanes all hold rvec|tvec in r, t.
+constexpr int REFIT_WAVES = 3;
+constexpr int REFIT_LDS_DOUBLES = REFIT_WAVES * LDS_DOUBLES + 3 * 13;
+
+__device__ __forceinline__ bool epnp_solve_three_waves(Points P, lds_double *lds, double r[3],
+                                                       double t[3])
 {
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const EpnpLds<1> S((lds_double *)lds);
-    Points P = make_points(obj, img, idx, n, K);
-    if (n >= 64) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (P.n >= 64) {
         P.first = lane;
         P.step = 64;
     }
-    double R[3][3], t[3], r[3];
-    epnp_pose<1, POSE_WAVE>(P, S, R, t, lane);
-    rodrigues_mat_to_vec(S, R, r);
+    const EpnpLds<1> S(lds + wave * LDS_DOUBLES);
+    lds_double *res = lds + REFIT_WAVES * LDS_DOUBLES;
+    double R[3][3], err;
+    epnp_pose<1, POSE_WAVE>(P, S, R, t, lane, wave + 1, &err);
     if (lane == 0) {
+        lds_double *out = res + 13 * wave;
+        out[0] = err;
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++)
+                out[1 + 3 * i + j] = R[i][j];
+            out[10 + i] = t[i];
+        }
+    }
+    __syncthreads();
+    if (wave != 0)
+        return false;
+    // N = 1; if (err2 < err1) N = 2; if (err3 < err[N]) N = 3
+    int best = 0;
+    if (res[13] < res[0])
+        best = 1;
+    if (res[26] < res[13 * best])
+        best = 2;
+    const lds_double *win = res + 13 * best;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            R[i][j] = win[1 + 3 * i + j];
+        t[i] = win[10 + i];
+    }
+    rodrigues_mat_to_vec(S, R, r);
+    return true;
+}
+
+// solvePnP(SOLVEPNP_EPNP) on rows idx[0..n) (idx may be null): model[6] = rvec|tvec.
+// One workgroup of three waves, one problem (epnp_solve_three_waves): a refit on thousands
+// of inliers costs less than a 5-point solve of one lane.
+__global__ __launch_bounds__(64 * REFIT_WAVES) void epnp_solve_kernel(
+    const float *__restrict__ obj, const float *__restrict__ img, const int32_t *__restrict__ idx,
+    int n, CameraK K, double *__restrict__ model)
+{
+    extern __shared__ double lds[];
+    double r[3], t[3];
+    if (epnp_solve_three_waves(make_points(obj, img, idx, n, K), (lds_double *)lds, r, t) &&
+        threadIdx.x == 0) {
         model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
         model[3] = t[0]; model[4] = t[1]; model[5] = t[2];
     }
 }
 
-// The end of solvePnPRansac for a batch, one wave per problem: the inliers of the problem's
-// best model (all rows where use_all_rows[b] != 0: a problem of exactly five rows has no
-// model) are listed in ascending row order, then EPnP is solved on them as in
-// epnp_solve_kernel.  Problem b owns rows [begins[b], ends[b]); its list (rows relative to
-// begins[b]) goes to idx_dev + begins[b], which the solve reads back, and to idx_out +
-// begins[b]; n_inliers[b] = its length; models_out[6b..] = rvec|tvec (left alone, like
-// idx_out, when fewer than 4 rows are listed, which a model with 5 or more inliers
-// cannot produce).  begins == nullptr: one problem, rows 0..one.rows, model one.best
-// (passed by value: a single call then reads no table).
-__global__ __launch_bounds__(64) void epnp_refit_batched_kernel(
+// The end of solvePnPRansac for a batch, one workgroup of three waves per problem: the
+// inliers of the problem's best model (all rows where use_all_rows[b] != 0: a problem of
+// exactly five rows has no model) are listed in ascending row order, then EPnP is solved on
+// them as in epnp_solve_kernel.  Problem b owns rows [begins[b], ends[b]); its list (rows
+// relative to begins[b]) goes to idx_dev + begins[b], which the solve reads back, and to
+// idx_out + begins[b]; n_inliers[b] = its length; models_out[6b..] = rvec|tvec (left
+// alone, like idx_out, when fewer than 4 rows are listed, which a model with 5 or more
+// inliers cannot produce).  Every wave builds the list for itself (the three write equal
+// values to the same words), so none waits for another before its solve.
+// begins == nullptr: one problem, rows 0..one.rows, model one.best (passed by value: a
+// single call then reads no table).
+__global__ __launch_bounds__(64 * REFIT_WAVES) void epnp_refit_batched_kernel(
     const float *__restrict__ obj, const float *__restrict__ img,
     const int32_t *__restrict__ begins, const int32_t *__restrict__ ends,
     const double *__restrict__ best_models, const uint8_t *__restrict__ use_all_rows,
@@ -1746,7 +1797,7 @@ __global__ __launch_bounds__(64) void epnp_refit_batched_kernel(
     int32_t *__restrict__ n_inliers, double *__restrict__ models_out)
 {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int b = blockIdx.x;
     const int64_t row0 = begins ? begins[b] : 0;
     const int rows = begins ? ends[b] - begins[b] : one.rows;
@@ -1773,24 +1824,18 @@ __global__ __launch_bounds__(64) void epnp_refit_batched_kernel(
             k += __builtin_popcountll(votes);
         }
     }
-    if (lane == 0)
+    if (threadIdx.x == 0)
         n_inliers[b] = k;
-    if (k < 4)
+    if (k < 4) // the same k in every wave: no wave is left waiting at the barrier below
         return;
     // the list was written by other lanes of this wave: make it visible to every lane's loads
     __threadfence();
-    for (int i = lane; i < k; i += 64)
-        idx_out[row0 + i] = list[i];
-    const EpnpLds<1> S((lds_double *)lds);
-    Points P = make_points(obj, img, list, k, K);
-    if (k >= 64) {
-        P.first = lane;
-        P.step = 64;
-    }
-    double R[3][3], t[3], r[3];
-    epnp_pose<1, POSE_WAVE>(P, S, R, t, lane);
-    rodrigues_mat_to_vec(S, R, r);
-    if (lane == 0) {
+    if (threadIdx.x < 64)
+        for (int i = lane; i < k; i += 64)
+            idx_out[row0 + i] = list[i];
+    double r[3], t[3];
+    if (epnp_solve_three_waves(make_points(obj, img, list, k, K), (lds_double *)lds, r, t) &&
+        threadIdx.x == 0) {
         double *model = models_out + (int64_t)b * 6;
         model[0] = r[0]; model[1] = r[1]; model[2] = r[2];
         model[3] = t[0]; model[4] = t[1]; model[5] = t[2];
@@ -1881,12 +1926,12 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
 hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,
                              CameraK K, double *d_model, hipStream_t stream)
 {
-    const size_t lds_bytes = (size_t)LDS_DOUBLES * sizeof(double);
+    const size_t lds_bytes = (size_t)REFIT_LDS_DOUBLES * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void *)epnp_solve_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
         return e;
-    epnp_solve_kernel<<<1, 64, lds_bytes, stream>>>(d_obj, d_img, d_idx, n, K, d_model);
+    epnp_solve_kernel<<<1, 64 * REFIT_WAVES, lds_bytes, stream>>>(d_obj, d_img, d_idx, n, K, d_model);
     return hipGetLastError();
 }
 
@@ -1900,8 +1945,8 @@ hipError_t epnp_refit_batched_launch(const float *d_obj, const float *d_img,
 {
     if (n_problems <= 0)
         return hipSuccess;
-    const size_t lds_bytes = (size_t)LDS_DOUBLES * sizeof(double);
-    epnp_refit_batched_kernel<<<n_problems, 64, lds_bytes, stream>>>(
+    const size_t lds_bytes = (size_t)REFIT_LDS_DOUBLES * sizeof(double);
+    epnp_refit_batched_kernel<<<n_problems, 64 * REFIT_WAVES, lds_bytes, stream>>>(
         d_obj, d_img, d_begins, d_ends, d_best_models, d_use_all_rows, one, K, thr2, d_idx,
         d_idx_out, d_n_inliers, d_models_out);
     return hipGetLastError();
