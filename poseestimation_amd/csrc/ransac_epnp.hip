@@ -1387,8 +1387,8 @@ enum PoseMode {
 // the result (one per problem).
 // HPW = problems per wave in the grouped modes (the lane stride between the members of
 // a group); the LDS element stride ST may be larger.
-// only = 1..3 (POSE_LANE / POSE_WAVE): run that candidate alone and report its R, t and
-// reprojection error *err_out; the caller applies the selection rule over the three.
+// only = 1..3: run that candidate alone and report its R, t and reprojection error
+// *err_out; the caller applies the selection rule over the three.
 template <int ST, PoseMode MODE = POSE_LANE, int HPW = ST>
 __device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3], double t[3],
                           int lane = 0, int only = 0, double *err_out = nullptr)
@@ -1427,7 +1427,7 @@ __device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S,
     rho[3] = dist2(e.cws[1], e.cws[2]);
     rho[4] = dist2(e.cws[1], e.cws[3]);
     rho[5] = dist2(e.cws[2], e.cws[3]);
-    if constexpr (MODE == POSE_HELPED) {
+    if (MODE == POSE_HELPED && only == 0) {
         // The three candidates (beta initialisations) are independent of one another
         // after find_betas_approx, and Gauss-Newton and the pose step are the same code
         // for each: the members of a group take different candidates at once.  L stays
@@ -1499,6 +1499,7 @@ __device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S,
         wave_sync();
         return member == 0;
     }
+    // one candidate after the other, or the one asked for (every member of a group runs it)
     double best_err = 0;
     for (int c = 1; c <= 3; c++) {
         if (only != 0 && c != only)
@@ -1522,7 +1523,7 @@ __device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S,
     }
     if (err_out)
         *err_out = best_err;
-    return true;
+    return MODE == POSE_HELPED ? member == 0 : true;
 }
 
 // cv::Rodrigues matrix -> vector (R re-orthonormalised by SVD first).
@@ -1663,6 +1664,66 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(const float *__restric
     double R[3][3], t[3], r[3];
     if (!epnp_pose<ST, HPW < 64 ? POSE_HELPED : POSE_LANE, HPW>(P, S, R, t, lane))
         return;
+    rodrigues_mat_to_vec(S, R, r);
+    PNP_STAMP(15);
+    double *m = models + (int64_t)h * 6;
+    m[0] = r[0]; m[1] = r[1]; m[2] = r[2];
+    m[3] = t[0]; m[4] = t[1]; m[5] = t[2];
+}
+
+// ransac_solve_kernel for batches so small that most of the GPU would idle: a workgroup of
+// THREE waves serves HPW hypotheses, wave w solving candidate w + 1 (beta initialisation)
+// of each on its own LDS copy after repeating the common part for itself, as in
+// epnp_solve_three_waves; the candidates' errors and poses meet in LDS behind the three
+// copies (HPW x 3 x 13 doubles) and wave 0 applies the selection rule.  Every operation
+// of a candidate is the one ransac_solve_kernel performs: the models are bit-identical.
+// Dynamic LDS: (3 * max(HPW, LDS_MIN_STRIDE) * LDS_DOUBLES + HPW * 39) doubles.
+template <int HPW>
+__global__ __launch_bounds__(64 * 3) void ransac_solve3_kernel(
+    const float *__restrict__ obj, const float *__restrict__ img, CameraK K,
+    const int32_t *__restrict__ subsets, const int32_t *__restrict__ begins, int hyp_per_problem,
+    int h0, int n_hyp, double *__restrict__ models)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane % HPW;
+    const int h = h0 + blockIdx.x * HPW + hl;
+    constexpr int ST = HPW < LDS_MIN_STRIDE ? LDS_MIN_STRIDE : HPW;
+    const EpnpLds<ST> S((lds_double *)lds + wave * (ST * LDS_DOUBLES) + hl);
+    lds_double *res = (lds_double *)lds + 3 * (ST * LDS_DOUBLES) + hl * 39;
+    const bool live = h < n_hyp; // a dead lane skips the solve but its wave reaches the barrier
+    double R[3][3], t[3], r[3];
+    bool reports = false;
+    if (live) {
+        const int64_t row0 = begins ? begins[h / hyp_per_problem] : 0;
+        const Points P =
+            make_points(obj + 3 * row0, img + 2 * row0, subsets + (int64_t)h * 5, 5, K);
+        double err;
+        reports = epnp_pose<ST, POSE_HELPED, HPW>(P, S, R, t, lane, wave + 1, &err);
+        if (reports) {
+            lds_double *out = res + 13 * wave;
+            out[0] = err;
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++)
+                    out[1 + 3 * i + j] = R[i][j];
+                out[10 + i] = t[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (wave != 0 || !reports)
+        return;
+    // N = 1; if (err2 < err1) N = 2; if (err3 < err[N]) N = 3
+    int best = 0;
+    if (res[13] < res[0])
+        best = 1;
+    if (res[26] < res[13 * best])
+        best = 2;
+    const lds_double *win = res + 13 * best;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            R[i][j] = win[1 + 3 * i + j];
+        t[i] = win[10 + i];
+    }
     rodrigues_mat_to_vec(S, R, r);
     PNP_STAMP(15);
     double *m = models + (int64_t)h * 6;
@@ -1860,6 +1921,24 @@ static hipError_t launch_solve(const float *d_obj, const float *d_img, CameraK K
     return hipGetLastError();
 }
 
+template <int HPW>
+static hipError_t launch_solve3(const float *d_obj, const float *d_img, CameraK K,
+                                const int32_t *d_subsets, const int32_t *d_begins,
+                                int hyp_per_problem, int h0, int n_hyp, double *d_models,
+                                hipStream_t stream)
+{
+    const size_t lds_bytes =
+        ((size_t)3 * (HPW < LDS_MIN_STRIDE ? LDS_MIN_STRIDE : HPW) * LDS_DOUBLES + HPW * 39) *
+        sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void *)ransac_solve3_kernel<HPW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess)
+        return e;
+    ransac_solve3_kernel<HPW><<<(n_hyp - h0 + HPW - 1) / HPW, 64 * 3, lds_bytes, stream>>>(
+        d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, n_hyp, d_models);
+    return hipGetLastError();
+}
+
 hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int n, CameraK K,
                                     const int32_t *d_subsets, const int32_t *d_begins,
                                     const int32_t *d_ends, int n_problems, int hyp_per_problem,
@@ -1878,6 +1957,9 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     // two lanes per hypothesis).  Fewer go 16 or 8 to a wave: more lanes per hypothesis
     // shorten its solve (8 lanes take all the independent Jacobi pairs of a step and
     // all three candidates at once) while the waves still fit the SIMDs in one round.
+    // One workgroup per CU's worth or less (a single solvePnPRansac call with OpenCV's default
+    // 100 iterations): three waves per 8 hypotheses, one per candidate.
+    const bool lone = n_hyp <= n_cus * 8;
     const bool tiny = n_hyp <= n_cus * 4 * 8;
     const bool small = n_hyp <= n_cus * 4 * 16;
     // A large batch goes down in rounds of one GPU-full of solves; the scoring of a
@@ -1888,7 +1970,10 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     hipError_t e;
     for (int h0 = 0; h0 < n_hyp; h0 += split ? round : n_hyp) {
         const int h1 = split ? (n_hyp - h0 > round ? h0 + round : n_hyp) : n_hyp;
-        if (tiny)
+        if (lone)
+            e = launch_solve3<8>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
+                                 d_models, stream);
+        else if (tiny)
             e = launch_solve<8>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
                                 d_models, stream);
         else if (small)
