@@ -481,9 +481,9 @@ __device__ __forceinline__ void jacobi_pair_test(LP<ST> At, LP<ST> W, const Jaco
     m.rotate = !(fabs(p) <= eps * sqrt(m.a * m.b));
 }
 
-// Rotation and rotated rows.
+// The rotation (c, s) of a pair past the convergence test.
 template <int N>
-__device__ __forceinline__ void jacobi_pair_math(const JacobiRow<N> &r, PairMath<N> &m)
+__device__ __forceinline__ void jacobi_pair_rotation(PairMath<N> &m, double &c, double &s)
 {
     const double p = m.p * 2;
     const double beta = m.a - m.b;
@@ -509,8 +509,15 @@ __device__ __forceinline__ void jacobi_pair_math(const JacobiRow<N> &r, PairMath
     double sum = ax + ay;
     KEEP(h); KEEP(sum);
     const double gamma = negligible ? sum : h;
-    double c, s;
     jacobi_rotation(p, beta, gamma, c, s);
+}
+
+// Rotation and rotated rows.
+template <int N>
+__device__ __forceinline__ void jacobi_pair_math(const JacobiRow<N> &r, PairMath<N> &m)
+{
+    double c, s;
+    jacobi_pair_rotation<N>(m, c, s);
     double na = 0, nb = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -593,6 +600,47 @@ __device__ __forceinline__ bool jacobi_pair_lds(LP<ST> At, LP<ST> W, int i, int 
         }
         W[i] = m.na;
         W[j] = m.nb;
+    }
+    return m.rotate;
+}
+
+// jacobi_pair_lds by TWO lanes: both load the two rows, test and compute the rotation, then
+// the first lane rotates and stores row i with its norm and the second (second == true)
+// row j with its norm, a third fewer fp64 instructions per lane.  Each row's elements and
+// norm are computed by the operations of jacobi_pair in their order (row j's element is
+// -s * v + c * aj either way), so the result is bit-identical.  True if the pair was rotated.
+template <int ST, int N>
+__device__ __forceinline__ bool jacobi_pair_lds_half(LP<ST> At, LP<ST> W, int i, int j, double eps,
+                                                     bool second)
+{
+    const LP<ST> Ai = At + i * N, Aj = At + j * N;
+    JacobiRow<N> r;
+    r.load(Ai, W[i]);
+    PairMath<N> m;
+    jacobi_pair_test<ST, N>(At, W, r, j, eps, m);
+    if (__builtin_amdgcn_ballot_w64(m.rotate) == 0)
+        return false;
+    double c, s;
+    jacobi_pair_rotation<N>(m, c, s);
+    if (__builtin_amdgcn_ballot_w64(m.rotate & !m.plain) != 0) { // hypot's special ranges:
+        jacobi_pair<ST, N>(At, W, r, j, eps, r.dirty); // both lanes do the whole pair alike
+        r.store(Ai, W[i]);
+        return r.dirty;
+    }
+    const double cv = second ? -s : c, cj = second ? c : s;
+    double out[N], norm2 = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const double t = cv * r.v[k] + cj * m.aj[k];
+        out[k] = t;
+        norm2 += t * t;
+    }
+    if (m.rotate) {
+        const LP<ST> row = second ? Aj : Ai;
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            row[k] = out[k];
+        W[second ? j : i] = norm2;
     }
     return m.rotate;
 }
@@ -778,6 +826,9 @@ __device__ void jacobi_sweeps_12_shared(LP<ST> At, LP<ST> W, int g, int hl)
         }
         return;
     }
+    // twelve or more lanes per matrix: two lanes per pair (a step has at most six pairs)
+    constexpr bool HALVES = G >= 12;
+    constexpr int PAIRS = HALVES ? G / 2 : G;
     bool rot_old = false, rot_new = false; // a rotation in sweep s - 1 / in sweep s
     for (int s = 0; s <= MAX_SWEEPS; s++) {
         for (int T0 = 0; T0 < PERIOD; T0++) {
@@ -786,13 +837,15 @@ __device__ void jacobi_sweeps_12_shared(LP<ST> At, LP<ST> W, int g, int hl)
             const int lo0 = T0 > N - 2 ? T0 - (N - 2) : 0, lo1 = T1 - (N - 2);
             const int c0 = s < MAX_SWEEPS ? (T0 >> 1) - lo0 + 1 : 0;
             const int c1 = OVERLAP && s > 0 && T1 <= LAST ? (T1 >> 1) - lo1 + 1 : 0;
-            for (int q0 = 0; q0 < c0 + c1; q0 += G) {
-                const int q = q0 + g;
+            for (int q0 = 0; q0 < c0 + c1; q0 += PAIRS) {
+                const int q = q0 + (HALVES ? g >> 1 : g);
                 if (q < c0 + c1) {
                     const bool old = OVERLAP && q >= c0;
                     const int i = old ? lo1 + q - c0 : lo0 + q;
                     const int j = (old ? T1 : T0) + 1 - i;
-                    const bool rotated = jacobi_pair_lds<ST, N>(At, W, i, j, eps);
+                    const bool rotated = HALVES
+                                             ? jacobi_pair_lds_half<ST, N>(At, W, i, j, eps, g & 1)
+                                             : jacobi_pair_lds<ST, N>(At, W, i, j, eps);
                     rot_old |= old & rotated;
                     rot_new |= !old & rotated;
                 }
@@ -1957,8 +2010,11 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     // two lanes per hypothesis).  Fewer go 16 or 8 to a wave: more lanes per hypothesis
     // shorten its solve (8 lanes take all the independent Jacobi pairs of a step and
     // all three candidates at once) while the waves still fit the SIMDs in one round.
-    // One workgroup per CU's worth or less (a single solvePnPRansac call with OpenCV's default
-    // 100 iterations): three waves per 8 hypotheses, one per candidate.
+    // One workgroup per CU or fewer (a single solvePnPRansac call with OpenCV's default 100
+    // iterations): three waves per 8 hypotheses, one per candidate; per 4 hypotheses where
+    // that still fits (16 lanes per hypothesis: two lanes per Jacobi pair).  Measured, solve
+    // only: 100 hypotheses 0.25 ms (one wave per 8) -> 0.21 -> 0.19 ms, 2048 0.25 -> 0.22 ms.
+    const bool lone4 = n_hyp <= n_cus * 4;
     const bool lone = n_hyp <= n_cus * 8;
     const bool tiny = n_hyp <= n_cus * 4 * 8;
     const bool small = n_hyp <= n_cus * 4 * 16;
@@ -1970,7 +2026,10 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     hipError_t e;
     for (int h0 = 0; h0 < n_hyp; h0 += split ? round : n_hyp) {
         const int h1 = split ? (n_hyp - h0 > round ? h0 + round : n_hyp) : n_hyp;
-        if (lone)
+        if (lone4)
+            e = launch_solve3<4>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
+                                 d_models, stream);
+        else if (lone)
             e = launch_solve3<8>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
                                  d_models, stream);
         else if (tiny)

@@ -94,7 +94,8 @@ int main(int argc, char **argv)
         const int hpw = atoi(argv[2]);
         for (int r = 0; r < 3; r++) {
             CK(hipEventRecord(e0));
-            if (hpw == 3) CK(launch_solve3<8>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0)); // 8 per workgroup of three waves
+            if (hpw == 5) CK(launch_solve3<4>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0)); // 4 per workgroup of three waves
+            else if (hpw == 3) CK(launch_solve3<8>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0)); // 8 per workgroup of three waves
             else if (hpw == 1) CK(launch_solve<1>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0));
             else if (hpw == 2) CK(launch_solve<2>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0));
             else if (hpw == 4) CK(launch_solve<4>(d_obj, d_img, K, d_sub, nullptr, H, 0, H, d_models, 0));
