@@ -30,7 +30,8 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
 hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,
                              CameraK K, double *d_model, hipStream_t stream);
 
-// The end of solvePnPRansac for a batch in one launch (one wave per problem): problem b owns
+// The end of solvePnPRansac for a batch in one launch (one workgroup of three waves per
+// problem, a wave per EPnP candidate): problem b owns
 // rows [d_begins[b], d_ends[b]); its inliers under d_best_models[6b..] (every row where
 // d_use_all_rows[b] != 0) are listed in ascending order, relative to d_begins[b], at
 // d_idx + d_begins[b] (device scratch the kernel reads back; as many entries as rows overall)

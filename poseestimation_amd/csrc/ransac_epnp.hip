@@ -23,6 +23,8 @@
 // Per-point quantities (barycentric coordinates, camera-frame points) are
 // recomputed where they are used instead of stored, so the same routine refits
 // on any number of inliers in O(1) memory.
+// Where few problems are in flight (a lone small call; the refit on the inliers) a
+// problem gets a workgroup of three waves, one per candidate, each on its own LDS copy.
 // Scoring is a second kernel with ONE HYPOTHESIS PER WAVEFRONT: the 64 lanes
 // stride over the correspondences and the inlier count is reduced with
 // ballot + popcount.
