@@ -326,3 +326,22 @@ def test_degenerate_samples_agree_with_oracle(posehip):
         assert np.array_equal(np.isnan(m), np.isnan(rm))
         fin = np.isfinite(rm)
         assert np.allclose(m[fin], rm[fin], rtol=1e-9, atol=1e-9)
+
+
+def test_every_solve_kernel_gives_the_same_models(posehip):
+    """The library picks the solve kernel by the number of hypotheses in the call (three
+    waves per 4 or per 8 hypotheses for a lone small call, one wave per 8, 16 or 32
+    beyond); every one performs the sequential statement's operations in its order, so a
+    hypothesis must get bit for bit the same model and count whatever the call's size, the
+    degenerate samples' NaNs included, and the oracle's counts on a sample."""
+    obj, img, R, t, _ = datagen.pnp_scene(n=400, outlier_frac=0.3, seed=57)
+    obj[:40] = obj[0]                      # some degenerate samples
+    sub = orc.ransac_subsets(400, 17000)
+    m_ref, c_ref = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, sub)       # 32 per wave
+    for h in (3, 100, 1021, 1024, 1025, 2048, 2049, 8192, 8193, 16384):
+        m, c = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, sub[:h])
+        assert np.array_equal(c, c_ref[:h]), h
+        assert np.array_equal(m.view(np.uint64), m_ref[:h].view(np.uint64)), h
+    rm, rc = orc.pnp_hypotheses(obj, img, datagen.CAMERA_K, sub[:256], threads=8)
+    assert np.array_equal(c_ref[:256], rc)
+    assert np.array_equal(np.isnan(m_ref[:256]), np.isnan(rm))
