@@ -219,3 +219,54 @@ def test_precomputed_rounds_equal_cyclic_sweeps_bitwise(name, G):
             if not rotated:
                 break
         assert n0 == n1 and A0.tobytes() == A1.tobytes()
+
+
+def pair_by_two_lanes(A, W, i, j, eps):
+    """jacobi_pair_lds_half in float64: both lanes read the rows as they stand, test and
+    compute the rotation; lane `second` then forms cv * A[i] + cj * A[j] with (cv, cj) =
+    (c, s) for row i and (-s, c) for row j, and its row's norm."""
+    a, b, p = W[i], W[j], 0.0
+    ri, rj = A[i].copy(), A[j].copy()
+    for k in range(A.shape[1]):
+        p += ri[k] * rj[k]
+    if abs(p) <= eps * math.sqrt(a * b):
+        return False
+    p *= 2.0
+    beta = a - b
+    gamma = math.hypot(p, beta)
+    if beta < 0:
+        s = math.sqrt((gamma - beta) * 0.5 / gamma)
+        c = p / (gamma * s * 2)
+    else:
+        c = math.sqrt((gamma + beta) / (gamma * 2))
+        s = p / (gamma * c * 2)
+    for second in (False, True):
+        cv, cj = (-s, c) if second else (c, s)
+        norm2 = 0.0
+        row = j if second else i
+        for k in range(A.shape[1]):
+            t = cv * ri[k] + cj * rj[k]
+            A[row, k] = t
+            norm2 += t * t
+        W[row] = norm2
+    return True
+
+
+def test_pair_split_over_two_lanes_equals_the_pair_bitwise():
+    eps = np.finfo(np.float64).eps * 10
+    rng = np.random.default_rng(12)
+    rotated = 0
+    for trial in range(300):
+        M = rng.standard_normal((12, 12)) * 10.0 ** rng.integers(-3, 4)
+        if trial % 3 == 0:
+            M = M @ M.T
+        A0, A1 = M.copy(), M.copy()
+        W0 = np.array([float(np.dot(r, r)) for r in A0])
+        W1 = W0.copy()
+        for i, j in cyclic(12):
+            r0 = pair(A0, W0, i, j, eps)
+            r1 = pair_by_two_lanes(A1, W1, i, j, eps)
+            assert r0 == r1
+            rotated += r0
+        assert A0.tobytes() == A1.tobytes() and W0.tobytes() == W1.tobytes()
+    assert rotated > 10000
