@@ -124,7 +124,7 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
         "dtype": "f64 solve, f32 reprojection error",
     }
     if rank == 0:
-        # whole solvePnPRansac calls (sampling, adaptive budget, inlier mask, refit) from host
+        # whole solvePnPRansac calls (sampling, adaptive budget, inlier list and refit) from host
         # buffers: a batch of frames of the reference's size in ONE call, and one frame per call
         import poseestimation_amd as pa
         fr = [datagen.pnp_scene(n=500, outlier_frac=0.3, seed=500 + f) for f in range(256)]
