@@ -1923,10 +1923,13 @@ __global__ __launch_bounds__(64 * REFIT_WAVES) void epnp_refit_batched_kernel(
     int k = 0;
     {
         const bool all = begins ? use_all_rows[b] != 0 : false;
-        double rv[3], tv[3];
-        for (int e = 0; e < 3; e++) {
-            rv[e] = begins ? best_models[(int64_t)b * 6 + e] : one.best[e];
-            tv[e] = begins ? best_models[(int64_t)b * 6 + 3 + e] : one.best[3 + e];
+        // constant indices: a loop over one.best would put the by-value struct in scratch
+        double rv[3] = {one.best[0], one.best[1], one.best[2]};
+        double tv[3] = {one.best[3], one.best[4], one.best[5]};
+        if (begins) {
+            const double *m = best_models + (int64_t)b * 6;
+            rv[0] = m[0]; rv[1] = m[1]; rv[2] = m[2];
+            tv[0] = m[3]; tv[1] = m[4]; tv[2] = m[5];
         }
         double Rm[9];
         rodrigues_vec_to_mat(rv, Rm);
