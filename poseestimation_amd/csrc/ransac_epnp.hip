@@ -213,6 +213,58 @@ __device__ __forceinline__ bool jacobi_small_pair(LP<ST> At, LP<ST> W, LP<ST> Vt
     return true;
 }
 
+// jacobi_small_pair by TWO lanes: both read the rows, test and compute the rotation; the
+// first then rotates and stores row i of At (with its norm) and of Vt, the second
+// (second == true) row j.  A row's elements and norm are computed by the operations of
+// jacobi_small_pair in their order, so the result is bit-identical.
+template <int ST, bool WITH_V, int M, int N>
+__device__ __forceinline__ bool jacobi_small_pair_half(LP<ST> At, LP<ST> W, LP<ST> Vt, int i, int j,
+                                                       double eps, bool second)
+{
+    const LP<ST> Ai = At + i * M, Aj = At + j * M;
+    double a = W[i], p = 0, b = W[j], c, s;
+    double ai[M], aj[M];
+#pragma unroll
+    for (int k = 0; k < M; k++) {
+        ai[k] = Ai[k];
+        aj[k] = Aj[k];
+    }
+    double vi[N], vj[N];
+    if (WITH_V) {
+        const LP<ST> Vi = Vt + i * N, Vj = Vt + j * N;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            vi[k] = Vi[k];
+            vj[k] = Vj[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < M; k++)
+        p += ai[k] * aj[k];
+    if (fabs(p) <= eps * sqrt(a * b))
+        return false;
+    p *= 2;
+    const double beta = a - b, gamma = hypot_cr(p, beta);
+    jacobi_rotation(p, beta, gamma, c, s);
+    const double cv = second ? -s : c, cj = second ? c : s;
+    const LP<ST> row = second ? Aj : Ai;
+    double norm2 = 0;
+#pragma unroll
+    for (int k = 0; k < M; k++) {
+        const double t = cv * ai[k] + cj * aj[k];
+        row[k] = t;
+        norm2 += t * t;
+    }
+    W[second ? j : i] = norm2;
+    if (WITH_V) {
+        const LP<ST> vrow = Vt + (second ? j : i) * N;
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            vrow[k] = cv * vi[k] + cj * vj[k];
+    }
+    return true;
+}
+
 // Lanes of a wave that share one problem's LDS copy (see PoseMode::POSE_HELPED): lane
 // `first + stride * g` is member g of `count`.  count == 1: the lane is on its own.
 struct LaneGroup {
@@ -270,12 +322,20 @@ __device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep,
             wave_sync();
             for (int iter = 0; iter < max_iter; iter++) {
                 bool changed = false;
+                // four or more members: two lanes per pair (a step of these sizes has at
+                // most two pairs)
+                const bool halves = grp.count >= 4;
+                const int per_round = halves ? grp.count >> 1 : grp.count;
+                const int slot = halves ? grp.member >> 1 : grp.member;
                 for (int T = 0; T <= 2 * N - 4; T++) {
                     const int lo = T > N - 2 ? T - (N - 2) : 0, hi = T >> 1;
-                    for (int i0 = lo; i0 <= hi; i0 += grp.count) {
-                        const int i = i0 + grp.member;
+                    for (int i0 = lo; i0 <= hi; i0 += per_round) {
+                        const int i = i0 + slot;
                         if (i <= hi)
-                            changed |= jacobi_small_pair<ST, WITH_V, M, N>(At, W, Vt, i, T + 1 - i, eps);
+                            changed |= halves ? jacobi_small_pair_half<ST, WITH_V, M, N>(
+                                                    At, W, Vt, i, T + 1 - i, eps, grp.member & 1)
+                                              : jacobi_small_pair<ST, WITH_V, M, N>(At, W, Vt, i,
+                                                                                    T + 1 - i, eps);
                         wave_sync();
                     }
                 }
