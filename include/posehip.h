@@ -151,6 +151,24 @@ ph_status ph_knn_hamming256_dev(const void *d_query, int64_t nq, const void *d_t
                                 int k, int32_t train_index_base, int32_t *d_out_idx,
                                 int32_t *d_out_dist, uint8_t *d_keep, float ratio, void *stream);
 
+/* ph_knn_hamming256_dev for callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart
+ * in the reference.  Same arguments, kernels and results as
+ * ph_knn_hamming256_dev, but the call's scratch (FP4 image of the train rows,
+ * per-split keys) lives in a fixed device array of PH_NOALLOC_SCRATCH_BYTES that
+ * every GPU the library runs on holds until the process ends, and the call
+ * makes no hipMalloc / hipFree or other allocating call.  A problem whose
+ * scratch does not fit (roughly nt * 128 + splits * nq * 8 bytes; 100k x 100k
+ * fits, 1M x 50k does not) is refused with PH_ERR_TOO_LARGE and a message naming
+ * the bytes needed.  Every call on a GPU shares that GPU's array: calls that
+ * overlap on one GPU (different streams without an ordering between them) race;
+ * the library does not order them.  Profiling events are not recorded. */
+#define PH_NOALLOC_SCRATCH_BYTES ((size_t)32 << 20)
+ph_status ph_knn_hamming256_noalloc_dev(const void *d_query, int64_t nq, const void *d_train,
+                                        int64_t nt, int k, int32_t train_index_base,
+                                        int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,
+                                        float ratio, void *stream);
+
 /* A batch of frames in one launch: frame f matches query rows
  * [q_offsets[f], q_offsets[f+1]) of d_query against train rows
  * [t_offsets[f], t_offsets[f+1]) of d_train, i.e. n_frames calls of

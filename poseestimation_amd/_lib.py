@@ -59,6 +59,9 @@ SIGNATURES = {
     "ph_knn_hamming256_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                         C.c_void_p]),
+    "ph_knn_hamming256_noalloc_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                                C.c_int, C.c_int32, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_float, C.c_void_p]),
     "ph_knn_hamming256_frames_dev": (C.c_int, [C.c_void_p, _i32p, C.c_void_p, _i32p, C.c_int,
                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_float, C.c_void_p]),

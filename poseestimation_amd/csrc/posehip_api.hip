@@ -19,6 +19,12 @@
 #include "ransac_epnp.h"
 #include "posehip.h"
 
+// Scratch of ph_knn_hamming256_noalloc_dev: the FP4 image of the train rows and the
+// per-split keys of one call.  Every GPU the library runs on holds its own copy at its
+// own address; `scratch` itself is only the host-side stand-in of the symbol, the
+// per-device address comes from hipGetSymbolAddress in ph_init (g_noalloc_ptr).
+static __device__ __align__(256) unsigned char scratch[PH_NOALLOC_SCRATCH_BYTES];
+
 // A train set resident in HBM (ph_db_upload); opaque to the C ABI.
 struct ph_db {
     void *d = nullptr;
@@ -157,6 +163,10 @@ struct Context {
 
 Context g_ctx;
 std::mutex g_mu;
+// Device address of `scratch` on every GPU ph_init has bound so far (each GPU has its own
+// copy of the array); looked up once per device with that device current.
+constexpr int MAX_DEVICES = 64;
+unsigned char *g_noalloc_ptr[MAX_DEVICES] = {};
 std::unordered_set<ph_db *> g_dbs; // live resident train sets (freed at ph_shutdown)
 
 
@@ -605,6 +615,14 @@ ph_status ph_init(int device)
         return fail(PH_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
                     device, prop.gcnArchName);
     g_ctx.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (device >= MAX_DEVICES)
+        return fail(PH_ERR_INVALID_ARG, "device %d beyond the %d this library tracks", device,
+                    MAX_DEVICES);
+    if (!g_noalloc_ptr[device]) { // this device's copy of `scratch` (the device is current)
+        void *p = nullptr;
+        PH_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_noalloc_ptr[device] = (unsigned char *)p;
+    }
     PH_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     PH_HIP(hipStreamCreateWithFlags(&g_ctx.pnp_overlap.side, hipStreamNonBlocking));
     PH_HIP(hipEventCreateWithFlags(&g_ctx.pnp_overlap.solved, hipEventDisableTiming));
@@ -780,6 +798,77 @@ ph_status ph_knn_hamming256_dev(const void *d_query, int64_t nq, const void *d_t
         return fail(PH_ERR_INVALID_ARG, "null output pointer");
     return knn_dev_locked(d_query, nq, d_train, nt, k, train_index_base, d_out_idx, d_out_dist,
                           d_keep, ratio, g_ctx.part, pick_stream(stream));
+}
+
+ph_status ph_knn_hamming256_noalloc_dev(const void *d_query, int64_t nq, const void *d_train,
+                                        int64_t nt, int k, int32_t train_index_base,
+                                        int32_t *d_out_idx, int32_t *d_out_dist, uint8_t *d_keep,
+                                        float ratio, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (k != 1 && k != 2)
+        return fail(PH_ERR_INVALID_ARG, "k must be 1 or 2 (got %d)", k);
+    if (d_keep && k != 2)
+        return fail(PH_ERR_INVALID_ARG, "the ratio test needs k == 2");
+    if (train_index_base < 0)
+        return fail(PH_ERR_INVALID_ARG, "negative train_index_base");
+    if ((s = check_rows(d_query, nq, "query")) != PH_OK)
+        return s;
+    if ((s = check_rows(d_train, nt, "train")) != PH_OK)
+        return s;
+    if (nq > 0 && (!d_out_idx || !d_out_dist))
+        return fail(PH_ERR_INVALID_ARG, "null output pointer");
+    // the device address of this GPU's copy of `scratch` (never the array's name)
+    unsigned char *ws = g_noalloc_ptr[g_ctx.device];
+    if (!ws)
+        return fail(PH_ERR_NOT_INITIALIZED, "no scratch address for device %d", g_ctx.device);
+    hipStream_t st = pick_stream(stream);
+    if (nq == 0)
+        return PH_OK;
+    if (nt == 0) {
+        fill_empty_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, st>>>(d_out_idx, d_out_dist,
+                                                                        d_keep, nq, k);
+        PH_HIP(hipGetLastError());
+        return PH_OK;
+    }
+    if (((uintptr_t)d_query & 15) || ((uintptr_t)d_train & 15))
+        return fail(PH_ERR_INVALID_ARG, "descriptor buffers must be 16-byte aligned");
+    if ((int64_t)train_index_base + nt - 1 > 0x7FFFFFFF)
+        return fail(PH_ERR_TOO_LARGE, "train_index_base + nt exceeds the 32-bit index range");
+    // Same kernels and plans as ph_knn_hamming256_dev; every word of scratch a call reads it
+    // has written before (the pre-pass writes the image, the distance kernel every key the
+    // merge folds), so nothing has to start at zero and the last call's contents do not matter.
+    if (g_ctx.knn_path == 2 || (g_ctx.knn_path == 0 && knn_mfma_pays(nq, nt))) {
+        const MfmaPlan mp = knn_mfma_plan(nq, nt, g_ctx.n_cus);
+        const size_t image = align256(knn_mfma_expanded_bytes(nt)), need = image + mp.part_bytes;
+        if (need > PH_NOALLOC_SCRATCH_BYTES)
+            return fail(PH_ERR_TOO_LARGE,
+                        "%lld x %lld needs %zu bytes of scratch; the allocation-free entry point "
+                        "holds %zu (use ph_knn_hamming256_dev)",
+                        (long long)nq, (long long)nt, need, (size_t)PH_NOALLOC_SCRATCH_BYTES);
+        PH_HIP(knn_mfma_launch(mp, d_query, nq, d_train, nt, k, train_index_base, ws,
+                               (uint32_t *)(ws + image), d_out_idx, d_out_dist, d_keep, ratio, st,
+                               nullptr));
+        g_ctx.last_path = 1;
+        return PH_OK;
+    }
+    const KnnPlan plan = knn_plan(nq, nt, g_ctx.n_cus);
+    if (plan.rows_per_split * (int64_t)plan.n_splits < nt)
+        return fail(PH_ERR_TOO_LARGE, "train set of %lld rows is too large for one call",
+                    (long long)nt);
+    if (plan.part_bytes > PH_NOALLOC_SCRATCH_BYTES)
+        return fail(PH_ERR_TOO_LARGE,
+                    "%lld x %lld needs %zu bytes of scratch; the allocation-free entry point "
+                    "holds %zu (use ph_knn_hamming256_dev)",
+                    (long long)nq, (long long)nt, plan.part_bytes,
+                    (size_t)PH_NOALLOC_SCRATCH_BYTES);
+    PH_HIP(knn_launch(plan, d_query, nq, d_train, nt, k, train_index_base, (uint32_t *)ws,
+                      d_out_idx, d_out_dist, d_keep, ratio, st, nullptr));
+    g_ctx.last_path = 0;
+    return PH_OK;
 }
 
 // One side (query or train) of a batch of frames: device rows, HOST offset table, the
