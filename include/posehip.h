@@ -315,6 +315,23 @@ int ph_knn_last_path(void);
  * matcher's roofline is this figure / 16.  Blocks until measured. */
 ph_status ph_valu_popcount_peak(int iters, double *lane_ops_per_s);
 
+/* Sustained fp64 VALU rates, in lane-operations per second, with 8 waves per SIMD on
+ * every CU: v_fma_f64 alone (two FLOP per lane-operation: the fp64 vector peak), and the
+ * v_mul_f64 + v_add_f64 mix (one FLOP each) that the RANSAC-EPnP solve is made of, being
+ * built without contraction so that it rounds like the sequential statement.  Blocks
+ * until measured. */
+ph_status ph_valu_fp64_peak(int iters, double *fma_lane_ops_per_s,
+                            double *mul_add_lane_ops_per_s);
+
+/* With profiling on (ph_set_profiling), ph_ransac_epnp_hypotheses[_batched]_dev records HIP
+ * events on its stream around the solve kernel of its first round of hypotheses, around
+ * the solve kernel of its last round (a call of at most one GPU-full -- 128 hypotheses per
+ * CU -- is a single round and both are the same launch) and around the last round's
+ * scoring kernel; this waits for that call and returns the three durations in
+ * milliseconds (any pointer may be NULL). */
+ph_status ph_ransac_last_timing(float *first_solve_ms, float *last_solve_ms,
+                                float *last_score_ms);
+
 /* Blocks until everything enqueued on `stream` (NULL = library stream) is done. */
 ph_status ph_stream_synchronize(void *stream);
 

@@ -64,6 +64,9 @@ struct DevBuf {
     {
         if (bytes <= cap)
             return hipSuccess;
+        // grow by at least half: a stream of slowly growing requests (keypoint counts
+        // creeping upward) reallocates O(log) times; hipFree synchronises the whole device
+        const size_t want = std::max(std::max(bytes, cap + cap / 2), (size_t)1 << 20);
         if (p) {
             hipError_t e = hipFree(p);
             p = nullptr;
@@ -71,7 +74,6 @@ struct DevBuf {
             if (e != hipSuccess)
                 return e;
         }
-        size_t want = std::max(bytes, (size_t)1 << 20);
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess)
             cap = want;
@@ -99,8 +101,8 @@ struct PinBuf {
     {
         if (bytes <= cap)
             return hipSuccess;
+        const size_t want = std::max(std::max(bytes, cap + cap / 2), (size_t)1 << 16);
         release();
-        size_t want = std::max(bytes, (size_t)1 << 16);
         hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
         if (e != hipSuccess) {
             p = nullptr;
@@ -159,6 +161,8 @@ struct Context {
     int last_path = 0;                      // distance kernel of the last k-NN call: 0 VALU, 1 MFMA
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // [4]: ahead of the FP4 pre-pass
     bool ev_valid = false;
+    hipEvent_t pnp_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // RANSAC solve / score
+    bool pnp_ev_valid = false;
 };
 
 Context g_ctx;
@@ -325,6 +329,19 @@ ph_status crosscheck_dev_locked(const void *d_q, int64_t nq, const void *d_t, in
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// The host entry points queue copies and kernels that read and write the pinned staging
+// buffers.  When one of them fails half-way, what it has queued must finish before the
+// next call repacks those buffers: unless disarmed (the success path has synchronised
+// already), the destructor waits for the library stream.
+struct DrainOnError {
+    bool armed = true;
+    ~DrainOnError()
+    {
+        if (armed && g_ctx.stream)
+            (void)hipStreamSynchronize(g_ctx.stream);
+    }
+};
 
 void pack_rows(uint8_t *dst, const uint8_t *src, int64_t n, size_t step)
 {
@@ -675,6 +692,9 @@ void ph_shutdown(void)
     for (hipEvent_t e : g_ctx.ev)
         if (e)
             (void)hipEventDestroy(e);
+    for (hipEvent_t e : g_ctx.pnp_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     g_ctx = Context();
 }
 
@@ -701,8 +721,12 @@ ph_status ph_set_profiling(int enable)
     if (enable && !g_ctx.ev[0])
         for (hipEvent_t &e : g_ctx.ev)
             PH_HIP(hipEventCreate(&e));
+    if (enable && !g_ctx.pnp_ev[0])
+        for (hipEvent_t &e : g_ctx.pnp_ev)
+            PH_HIP(hipEventCreate(&e));
     g_ctx.profiling = enable != 0;
     g_ctx.ev_valid = false;
+    g_ctx.pnp_ev_valid = false;
     return PH_OK;
 }
 
@@ -770,9 +794,47 @@ ph_status ph_valu_popcount_peak(int iters, double *lane_ops_per_s)
         return s;
     if (iters < 1 || !lane_ops_per_s)
         return fail(PH_ERR_INVALID_ARG, "iters must be >= 1 and the output non-null");
+    if ((s = scratch_guard(g_ctx.stream)) != PH_OK) // tmp_i is cross-check workspace as well
+        return s;
     PH_HIP(g_ctx.tmp_i.reserve((size_t)g_ctx.n_cus * 8 * 256 * sizeof(uint32_t)));
     PH_HIP(valu_popcount_peak(g_ctx.n_cus, iters, (uint32_t *)g_ctx.tmp_i.p, g_ctx.stream,
                               lane_ops_per_s));
+    return PH_OK;
+}
+
+ph_status ph_valu_fp64_peak(int iters, double *fma_lane_ops_per_s,
+                            double *mul_add_lane_ops_per_s)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (iters < 1 || !fma_lane_ops_per_s || !mul_add_lane_ops_per_s)
+        return fail(PH_ERR_INVALID_ARG, "iters must be >= 1 and the outputs non-null");
+    if ((s = scratch_guard(g_ctx.stream)) != PH_OK) // tmp_d is cross-check workspace as well
+        return s;
+    PH_HIP(g_ctx.tmp_d.reserve((size_t)g_ctx.n_cus * 8 * 256 * sizeof(double)));
+    PH_HIP(valu_fp64_peak(g_ctx.n_cus, iters, (double *)g_ctx.tmp_d.p, g_ctx.stream,
+                          fma_lane_ops_per_s, mul_add_lane_ops_per_s));
+    return PH_OK;
+}
+
+ph_status ph_ransac_last_timing(float *first_solve_ms, float *last_solve_ms, float *last_score_ms)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (!g_ctx.pnp_ev_valid)
+        return fail(PH_ERR_INVALID_ARG,
+                    "no profiled RANSAC hypotheses call (ph_set_profiling(1) first)");
+    PH_HIP(hipEventSynchronize(g_ctx.pnp_ev[4]));
+    if (first_solve_ms)
+        PH_HIP(hipEventElapsedTime(first_solve_ms, g_ctx.pnp_ev[0], g_ctx.pnp_ev[1]));
+    if (last_solve_ms)
+        PH_HIP(hipEventElapsedTime(last_solve_ms, g_ctx.pnp_ev[2], g_ctx.pnp_ev[3]));
+    if (last_score_ms)
+        PH_HIP(hipEventElapsedTime(last_score_ms, g_ctx.pnp_ev[3], g_ctx.pnp_ev[4]));
     return PH_OK;
 }
 
@@ -1083,9 +1145,11 @@ ph_status ph_knn_hamming256(const uint8_t *query, int nq, size_t q_step, const u
     if (!out_idx || !out_dist)
         return fail(PH_ERR_INVALID_ARG, "null output pointer");
     HostResult r;
+    DrainOnError drain;
     if ((s = host_match_locked(query, nq, q_step, train, nt, t_step, MatchMode::Knn, k, 0.f, r)) !=
         PH_OK)
         return s;
+    drain.armed = false;
     memcpy(out_idx, r.idx, (size_t)nq * k * sizeof(int32_t));
     memcpy(out_dist, r.dist, (size_t)nq * k * sizeof(int32_t));
     return PH_OK;
@@ -1111,8 +1175,10 @@ ph_status host_match_list(const uint8_t *query, int nq, size_t q_step, const uin
         return fail(PH_ERR_INVALID_ARG, "null output pointer");
     const int k = mode == MatchMode::Ratio ? 2 : 1;
     HostResult r;
+    DrainOnError drain;
     if ((s = host_match_locked(query, nq, q_step, train, nt, t_step, mode, k, ratio, r)) != PH_OK)
         return s;
+    drain.armed = false;
     int n = 0;
     for (int i = 0; i < nq; i++) {
         const bool kept = mode == MatchMode::Ratio ? r.keep[i] != 0 : r.idx[(size_t)i * k] >= 0;
@@ -1276,6 +1342,7 @@ ph_status ph_db_knn_hamming256(const ph_db *db, const uint8_t *query, int64_t nq
         return fail(PH_ERR_INVALID_ARG, "null output pointer");
     hipStream_t st = g_ctx.stream;
     const void *d_q = nullptr, *d_unused = nullptr;
+    DrainOnError drain;
     if ((s = upload_descriptors(query, nq, q_step, nullptr, 0, 32, st, &d_q, &d_unused)) != PH_OK)
         return s;
     const size_t n_out = (size_t)nq * k;
@@ -1287,6 +1354,7 @@ ph_status ph_db_knn_hamming256(const ph_db *db, const uint8_t *query, int64_t nq
                             g_ctx.part, st, const_cast<ph_db *>(db))) != PH_OK)
         return s;
     PH_HIP(hipStreamSynchronize(st));
+    drain.armed = false;
     memcpy(out_idx, hb, n_out * sizeof(int32_t));
     memcpy(out_dist, hb + dist_off, n_out * sizeof(int32_t));
     if (keep)
@@ -1338,9 +1406,11 @@ ph_status ph_ransac_epnp_hypotheses_dev(const float *d_obj, const float *d_img, 
     if (n < 5 || n_hyp < 0 || (n_hyp > 0 && (!d_subsets || !d_models || !d_counts)))
         return fail(PH_ERR_INVALID_ARG, "need >= 5 correspondences and non-null buffers");
     const double thr = reproj_err;
+    hipEvent_t *ev = g_ctx.profiling && n_hyp > 0 ? g_ctx.pnp_ev : nullptr;
     PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, camera_of(K), d_subsets, nullptr, nullptr, 1,
                                     n_hyp, (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
-                                    pick_stream(stream), &g_ctx.pnp_overlap));
+                                    pick_stream(stream), &g_ctx.pnp_overlap, ev));
+    g_ctx.pnp_ev_valid = ev != nullptr;
     return PH_OK;
 }
 
@@ -1365,10 +1435,12 @@ ph_status ph_ransac_epnp_hypotheses_batched_dev(const float *d_obj, const float 
     if (!d_point_offsets || !d_subsets || !d_models || !d_counts)
         return fail(PH_ERR_INVALID_ARG, "null pointer");
     const double thr = reproj_err;
+    hipEvent_t *ev = g_ctx.profiling ? g_ctx.pnp_ev : nullptr;
     PH_HIP(ransac_hypotheses_launch(d_obj, d_img, 0, camera_of(K), d_subsets, d_point_offsets,
                                     d_point_offsets + 1, n_problems, hyp_per_problem,
                                     (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
-                                    pick_stream(stream), &g_ctx.pnp_overlap));
+                                    pick_stream(stream), &g_ctx.pnp_overlap, ev));
+    g_ctx.pnp_ev_valid = ev != nullptr;
     return PH_OK;
 }
 
@@ -1414,11 +1486,13 @@ ph_status ph_solvepnp_epnp(const float *obj, const float *img, int n, const doub
         return fail(PH_ERR_INVALID_ARG, "EPnP needs >= 4 correspondences and output pointers");
     hipStream_t st = g_ctx.stream;
     PnpDev d;
+    DrainOnError drain;
     if ((s = upload_pnp(obj, img, n, nullptr, 0, st, d)) != PH_OK)
         return s;
     PH_HIP(g_ctx.h_out.reserve(6 * sizeof(double)));
     PH_HIP(epnp_solve_launch(d.obj, d.img, nullptr, n, camera_of(K), (double *)g_ctx.h_out.dp, st));
     PH_HIP(hipStreamSynchronize(st));
+    drain.armed = false;
     const double *m = (const double *)g_ctx.h_out.p;
     memcpy(rvec, m, 3 * sizeof(double));
     memcpy(tvec, m + 3, 3 * sizeof(double));
@@ -1455,6 +1529,7 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
     const double thr = reproj_err;
     const float thr2 = (float)(thr * thr);
     hipStream_t st = g_ctx.stream;
+    DrainOnError drain; // stays armed: one more wait on an idle stream costs nothing here
 
     if (n == model_points) { // run(): count == modelPoints -> one solve, every point an inlier
         PnpDev d;
@@ -1481,13 +1556,17 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
     // over the counts, and chunks beyond the shrunken budget are never launched.
     int niters = std::max(iterations_count, 1);
     const int total = niters;
-    const int32_t *subsets = g_subsets.get(rng_state, n, total);
+    // samples are drawn and uploaded one chunk at a time: a budget the adaptive rule cuts
+    // after a few hundred iterations never pays for the samples of its nominal count
+    const int chunk = 4096, cmax = std::min(total, chunk);
     PnpDev d;
-    if ((s = upload_pnp(obj, img, n, subsets, (size_t)total, st, d)) != PH_OK)
+    if ((s = upload_pnp(obj, img, n, g_subsets.get(rng_state, n, cmax), (size_t)cmax, st, d)) !=
+        PH_OK)
         return s;
+    int32_t *h_sub = (int32_t *)((uint8_t *)g_ctx.h_in.p +
+                                 ((const uint8_t *)d.subsets - (const uint8_t *)g_ctx.d_in.p));
     // pinned results, written by the kernels: models | counts | refit model | inlier count |
     // inlier list
-    const int chunk = 4096, cmax = std::min(total, chunk);
     const size_t counts_off = align256((size_t)cmax * 6 * sizeof(double));
     const size_t best_off = counts_off + align256((size_t)cmax * sizeof(int32_t));
     const size_t refit_off = best_off, ninl_off = refit_off + 256, list_off = ninl_off + 256;
@@ -1499,7 +1578,13 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
     double best[6] = {0, 0, 0, 0, 0, 0};
     for (int base = 0; base < total && base < niters; base += chunk) {
         const int m = std::min(chunk, total - base);
-        PH_HIP(ransac_hypotheses_launch(d.obj, d.img, n, cam, d.subsets + (size_t)base * 5, nullptr,
+        if (base > 0) { // the previous chunk has been waited for: its samples can be replaced
+            memcpy(h_sub, g_subsets.get(rng_state, n, base + m) + (size_t)base * 5,
+                   (size_t)m * 5 * sizeof(int32_t));
+            PH_HIP(hipMemcpyAsync((void *)d.subsets, h_sub, (size_t)m * 5 * sizeof(int32_t),
+                                  hipMemcpyHostToDevice, st));
+        }
+        PH_HIP(ransac_hypotheses_launch(d.obj, d.img, n, cam, d.subsets, nullptr,
                                         nullptr, 1, m, thr2, (double *)db,
                                         (int32_t *)(db + counts_off), g_ctx.n_cus, st));
         PH_HIP(hipStreamSynchronize(st));
@@ -1588,6 +1673,7 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
     const double thr = reproj_err;
     const float thr2 = (float)(thr * thr);
     hipStream_t st = g_ctx.stream;
+    DrainOnError drain; // stays armed: one more wait on an idle stream costs nothing here
 
     struct Prob {
         int n, niters, iter = 0, max_good = 0;

@@ -24,7 +24,17 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
                                     const int32_t *d_subsets, const int32_t *d_begins,
                                     const int32_t *d_ends, int n_problems, int hyp_per_problem,
                                     float thr2, double *d_models, int32_t *d_counts, int n_cus,
-                                    hipStream_t stream, const RansacOverlap *overlap = nullptr);
+                                    hipStream_t stream, const RansacOverlap *overlap = nullptr,
+                                    hipEvent_t *events = nullptr);
+// events, when given (five of them), are recorded on `stream` around the first round's solve
+// kernel [0, 1], the last round's solve kernel [2, 3] (the same launch when the call is one
+// round) and the last round's scoring kernel [3, 4].
+
+// Sustained fp64 VALU rates in lane-operations per second with 8 waves per SIMD on every
+// CU: v_fma_f64 alone, and the v_mul_f64 + v_add_f64 mix of code built without
+// contraction.  d_scratch: n_cus * 8 * 256 doubles.  Blocks until measured.
+hipError_t valu_fp64_peak(int n_cus, int iters, double *d_scratch, hipStream_t stream,
+                          double *fma_per_s, double *mul_add_per_s);
 
 // EPnP on rows d_idx[0..n) (d_idx may be null: rows 0..n) -> d_model = rvec|tvec.
 hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,

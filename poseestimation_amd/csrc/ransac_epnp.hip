@@ -2061,7 +2061,8 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
                                     const int32_t *d_subsets, const int32_t *d_begins,
                                     const int32_t *d_ends, int n_problems, int hyp_per_problem,
                                     float thr2, double *d_models, int32_t *d_counts, int n_cus,
-                                    hipStream_t stream, const RansacOverlap *overlap)
+                                    hipStream_t stream, const RansacOverlap *overlap,
+                                    hipEvent_t *events)
 {
     const int64_t total = (int64_t)n_problems * hyp_per_problem;
     if (total <= 0)
@@ -2091,6 +2092,11 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     hipError_t e;
     for (int h0 = 0; h0 < n_hyp; h0 += split ? round : n_hyp) {
         const int h1 = split ? (n_hyp - h0 > round ? h0 + round : n_hyp) : n_hyp;
+        const bool first = h0 == 0;
+        if (events && first && (e = hipEventRecord(events[0], stream)) != hipSuccess)
+            return e;
+        if (events && h1 == n_hyp && (e = hipEventRecord(events[2], stream)) != hipSuccess)
+            return e;
         if (lone4)
             e = launch_solve3<4>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
                                  d_models, stream);
@@ -2109,6 +2115,10 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
         if (e != hipSuccess)
             return e;
         const bool last = h1 == n_hyp;
+        if (events && first && (e = hipEventRecord(events[1], stream)) != hipSuccess)
+            return e;
+        if (events && last && (e = hipEventRecord(events[3], stream)) != hipSuccess)
+            return e;
         hipStream_t ss = stream;
         if (split && !last) {
             if ((e = hipEventRecord(overlap->solved, stream)) != hipSuccess)
@@ -2122,6 +2132,8 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
                                                                h0, h1, thr2, d_counts);
         if ((e = hipGetLastError()) != hipSuccess)
             return e;
+        if (events && last && (e = hipEventRecord(events[4], stream)) != hipSuccess)
+            return e;
     }
     if (split) { // the caller's stream continues only after the side stream's scoring
         if ((e = hipEventRecord(overlap->scored, overlap->side)) != hipSuccess)
@@ -2130,6 +2142,77 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
             return e;
     }
     return hipSuccess;
+}
+
+// ---- fp64 VALU peak -------------------------------------------------------------
+// Eight independent chains per lane of v_fma_f64 (FMA = true) or of v_mul_f64 + v_add_f64
+// pairs (the solve is built without contraction, so this is its instruction mix), 8 waves
+// per SIMD on every CU.
+template <bool FMA>
+__global__ __launch_bounds__(256) void fp64_peak_kernel(double *out, double a, double b, int iters)
+{
+    double x0 = a + threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5,
+           x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (FMA)
+                asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n"
+                             "v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
+                             "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n"
+                             "v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6),
+                               "+v"(x7)
+                             : "v"(a), "v"(b));
+            else
+                asm volatile("v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %8\n"
+                             "v_mul_f64 %2, %2, %8\n v_mul_f64 %3, %3, %8\n"
+                             "v_add_f64 %4, %4, %9\n v_add_f64 %5, %5, %9\n"
+                             "v_add_f64 %6, %6, %9\n v_add_f64 %7, %7, %9\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6),
+                               "+v"(x7)
+                             : "v"(a), "v"(b));
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+
+hipError_t valu_fp64_peak(int n_cus, int iters, double *d_scratch, hipStream_t stream,
+                          double *fma_per_s, double *mul_add_per_s)
+{
+    const int blocks = n_cus * 8; // 8 workgroups x 4 waves per CU = 8 waves per SIMD
+    hipEvent_t e0, e1;
+    hipError_t e;
+    if ((e = hipEventCreate(&e0)) != hipSuccess)
+        return e;
+    if ((e = hipEventCreate(&e1)) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return e;
+    }
+    float best[2] = {0.f, 0.f};
+    for (int form = 0; form < 2 && e == hipSuccess; form++)
+        for (int r = 0; r < 4; r++) { // first pass warms up
+            (void)hipEventRecord(e0, stream);
+            if (form == 0)
+                fp64_peak_kernel<true><<<blocks, 256, 0, stream>>>(d_scratch, 1.0000001, 1e-9, iters);
+            else
+                fp64_peak_kernel<false><<<blocks, 256, 0, stream>>>(d_scratch, 1.0000001, 1e-9, iters);
+            (void)hipEventRecord(e1, stream);
+            if ((e = hipEventSynchronize(e1)) != hipSuccess)
+                break;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (r > 0 && (best[form] == 0.f || ms < best[form]))
+                best[form] = ms;
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess)
+        return e;
+    const double ops = (double)blocks * 256.0 * (double)iters * 8 * 8;
+    *fma_per_s = ops / (best[0] * 1e-3);
+    *mul_add_per_s = ops / (best[1] * 1e-3);
+    return hipGetLastError();
 }
 
 hipError_t epnp_solve_launch(const float *d_obj, const float *d_img, const int32_t *d_idx, int n,

@@ -26,8 +26,9 @@ def rotation_error(r_est, r_gt):
     """Frobenius ||R_gt - R_est|| / ||R_est||  (Evaluation.py:9-15).
 
     The reference passes both matrices through scipy's Rotation.from_matrix /
-    as_matrix first, which projects them onto SO(3); the same projection is done
-    here with an SVD (nearest rotation, determinant +1).
+    as_matrix first.  For an input that is not orthogonal scipy (1.15) takes the nearest
+    rotation by SVD, and so does this function (the golden file holds such cases, equal
+    to 1e-12); for a determinant <= 0 scipy raises ValueError, and so does this function.
     """
     q_est = _nearest_rotation(r_est)
     q_gt = _nearest_rotation(r_gt)
@@ -36,6 +37,9 @@ def rotation_error(r_est, r_gt):
 
 def _nearest_rotation(R):
     R = np.asarray(R, dtype=np.float64)
+    if not np.linalg.det(R) > 0:
+        raise ValueError("Non-positive determinant (left-handed or null coordinate frame) in "
+                         "rotation matrix")
     if abs(np.linalg.det(R) - 1.0) < 1e-12 and np.allclose(R @ R.T, np.eye(3), atol=1e-12):
         return R
     U, _, Vt = np.linalg.svd(R)

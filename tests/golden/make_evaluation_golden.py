@@ -50,7 +50,16 @@ for i in range(6):
                       rotation_error=float(ref.rotation_error(R_pred, R_gt)),
                       add=float(ref.compute_add_score(pts, diameter, R_pred, t_pred, R_gt, t_gt)),
                       adds=float(ref.compute_adds_score(pts, diameter, R_pred, t_pred, R_gt, t_gt))))
+# slightly and grossly non-orthogonal inputs: scipy's Rotation.from_matrix (1.15: nearest
+# rotation by SVD) projects them before the reference compares; rotation error only
+rng2 = np.random.default_rng(5)
+nonorth = []
+for eps in (1e-6, 1e-3, 1e-1):
+    R_gt = rot(rng2.normal(size=3), 1.0)
+    R_pred = rot(rng2.normal(size=3), 0.1) @ R_gt + rng2.normal(size=(3, 3)) * eps
+    nonorth.append(dict(R_pred=R_pred.tolist(), R_gt=R_gt.tolist(),
+                        rotation_error=float(ref.rotation_error(R_pred, R_gt))))
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "evaluation.json")
 json.dump({"_about": "outputs of the reference's src/evaluation/Evaluation.py (numpy %s)" % np.__version__,
-           "cases": cases}, open(out, "w"), indent=1)
+           "cases": cases, "non_orthogonal_rotation_cases": nonorth}, open(out, "w"), indent=1)
 print("wrote", out, len(cases), "cases")

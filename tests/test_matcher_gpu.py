@@ -343,6 +343,61 @@ def test_train_set_beyond_one_key_range(posehip):
     assert idx[2, 0] == nt - 1 and dist[2, 0] == 0
 
 
+@pytest.mark.parametrize("knn_path,nq", [("matrix_cores", 1_000_000), ("popcount", 65_536)],
+                         indirect=["knn_path"])
+def test_ten_million_train_rows_unsharded_and_eight_shards(posehip, nq):
+    """BASELINE configs[4]'s train set on one GPU: 10 000 000 train rows (1M queries on the
+    matrix cores, 65 536 on the popcount kernel), once as one call and once as 8 contiguous
+    shards searched with train_index_base and folded by ph_knn_merge_dev -- the single-GPU
+    form of the train-sharded job.  96 sampled query rows are checked against the oracle
+    on all 10M rows (exact copies planted on both sides of shard boundaries decide
+    tie-breaks across shards); both forms must agree on every row."""
+    import torch
+    from poseestimation_amd.distributed import block_bounds
+    nt, n_shards = 10_000_000, 8
+    t = datagen.random_descriptors(nt, 5)
+    q = datagen.random_descriptors(nq, 1005)
+    cut = block_bounds(nt, n_shards, 3)[0]           # first row of shard 3
+    rows = np.random.default_rng(3).choice(nq, 96, replace=False)
+    t[cut - 1] = q[rows[0]]                          # equal rows either side of a boundary
+    t[cut] = q[rows[0]]
+    t[nt - 1] = q[rows[1]]                           # last row of the last shard
+    t[17] = q[rows[2]]
+    t[cut + 5] = q[rows[2]]                          # first copy wins, second is the runner-up
+    d_q, d_t = _dev(q), _dev(t)
+    idx, dist, keep = gpu_knn_dev(posehip, d_q, d_t, 2, ratio=0.75)
+    ci, cd = [], []
+    for s in range(n_shards):
+        lo, hi = block_bounds(nt, n_shards, s)
+        i, d, _ = gpu_knn_dev(posehip, d_q, d_t[lo:hi], 2, base=lo)
+        ci.append(i)
+        cd.append(d)
+    all_i, all_d = torch.stack(ci).contiguous(), torch.stack(cd).contiguous()
+    m_i, m_d = torch.empty_like(idx), torch.empty_like(dist)
+    m_k = torch.empty_like(keep)
+    torch.cuda.synchronize()
+    posehip.check(posehip.load().ph_knn_merge_dev(
+        all_i.data_ptr(), all_d.data_ptr(), n_shards, nq, 2, m_i.data_ptr(), m_d.data_ptr(),
+        m_k.data_ptr(), 0.75, None))
+    posehip.check(posehip.load().ph_stream_synchronize(None))
+    assert torch.equal(m_i, idx) and torch.equal(m_d, dist) and torch.equal(m_k, keep)
+    idx, dist, keep = idx.cpu().numpy(), dist.cpu().numpy(), keep.cpu().numpy()
+    ridx, rdist = orc.knn(q[rows], t, 2, threads=8)
+    assert np.array_equal(idx[rows], ridx) and np.array_equal(dist[rows], rdist)
+    kept = {m[0] for m in orc.ratio_filter(ridx, rdist, 0.75)}
+    assert {i for i in range(96) if keep[rows[i]]} == kept
+    assert idx[rows[0]].tolist() == [cut - 1, cut] and dist[rows[0]].tolist() == [0, 0]
+    assert idx[rows[1], 0] == nt - 1 and dist[rows[1], 0] == 0
+    assert idx[rows[2]].tolist() == [17, cut + 5]
+    # properties of every row: ordered pairs of distinct rows in range, true distances
+    assert (dist[:, 0] <= dist[:, 1]).all() and (idx[:, 0] != idx[:, 1]).all()
+    assert idx.min() >= 0 and idx.max() < nt
+    sel = np.random.default_rng(4).choice(nq, 4096, replace=False)
+    for r in range(2):
+        true = np.unpackbits(q[sel] ^ t[idx[sel, r]], axis=1).sum(axis=1)
+        assert np.array_equal(true, dist[sel, r])
+
+
 def test_index_base_and_overflow_guard(posehip):
     q = datagen.random_descriptors(70, 91)
     t = datagen.random_descriptors(300, 92)
