@@ -10,12 +10,26 @@ nothing and no collective is on the data path.  The same frames issued as one
 `ph_knn_hamming256_dev` call each are timed beside it (`per_call`), and so is the same
 step on the popcount kernel (`popcount_kernel`) when the matrix cores ran it.
 
+`python bench.py --gpus N` started bare (no WORLD_SIZE in the environment) launches the N
+ranks itself, as child processes of a parent that never touches the GPU; under
+torch.distributed.run it is one of the ranks.  Beside the frame-sharded headline every
+run also times the train-sharded form of the matcher (BASELINE configs[4] scaled to the
+rank count: queries replicated, train rows in contiguous shards, one all-gather of the
+per-shard candidates, merge) and reports it as `train_sharded`.
+
+The timed region is never shorter than --min-seconds: if the requested steps finish
+sooner they are raised (the same number on every rank) and the region is timed again;
+`steps` is the number actually timed, `steps_requested` what the command line asked for.
+
 Prints one JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,7 +58,33 @@ def parse():
     ap.add_argument("--ransac-steps", type=int, default=10)
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the default) or gloo (rehearsing N ranks on fewer GPUs)")
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="shortest timed region; steps are raised to reach it")
+    ap.add_argument("--min-warmup-seconds", type=float, default=0.05)
+    ap.add_argument("--shard-nq", type=int, default=1_000_000,
+                    help="train-sharded leg: queries (replicated on every rank)")
+    ap.add_argument("--shard-nt", type=int, default=1_250_000,
+                    help="train-sharded leg: train rows per rank (BASELINE configs[4]: 10M / 8)")
+    ap.add_argument("--shard-steps", type=int, default=3)
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` started bare: start the N ranks as children (one process per GPU,
+    torch.distributed.run on 127.0.0.1) from this process, which has made no GPU call and
+    makes none, and pass their output and exit code on."""
+    import torch
+    have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    if args.dist_backend == "nccl" and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def all_reduce_max(value, torch, dist, dev, backend):
@@ -52,6 +92,108 @@ def all_reduce_max(value, torch, dist, dev, backend):
     t = torch.tensor([value], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def timed_region(step, steps, warmup, min_seconds, min_warmup_seconds, torch, dist, dev, world,
+                 backend):
+    """Warm up (at least `warmup` steps and `min_warmup_seconds`), then time `steps` steps
+    between barrier + synchronize on both sides, MAX over ranks.  A region shorter than
+    `min_seconds` is timed again with proportionally more steps (every rank derives the same
+    count from the all-reduced time).  Returns (seconds, steps timed)."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def run(n):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        return all_reduce_max(el, torch, dist, dev, backend) if world > 1 else el
+
+    done, w0 = 0, time.perf_counter()
+    while done < warmup or time.perf_counter() - w0 < min_warmup_seconds:
+        step()
+        done += 1
+        if done % 16 == 0:
+            torch.cuda.synchronize()   # bound the queue while the clock is being read
+    el = run(steps)
+    for _ in range(3):
+        if el >= min_seconds:
+            break
+        steps = int(math.ceil(steps * min_seconds * 1.15 / max(el, 1e-6)))
+        el = run(steps)
+    return el, steps
+
+
+def ransac_roofline(args, torch, lib, _lib, step, problems, hyps, n_points):
+    """Roofline of the RANSAC half: the solve kernel (fp64 VALU) and, beside it, the scoring
+    kernel, timed with HIP events on the launch stream inside the batched step."""
+    a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+    _lib.check(lib.ph_set_profiling(1))
+    first, last, score = [], [], []
+    for r in range(14):
+        step()
+        step()
+        _lib.check(lib.ph_ransac_last_timing(C.byref(a), C.byref(b), C.byref(c)))
+        if r >= 2:
+            first.append(a.value)
+            last.append(b.value)
+            score.append(c.value)
+    _lib.check(lib.ph_set_profiling(0))
+    torch.cuda.synchronize()
+    fma, mix = C.c_double(0), C.c_double(0)
+    _lib.check(lib.ph_valu_fp64_peak(2000, C.byref(fma), C.byref(mix)))
+    counts = json.load(open(os.path.join(ROOT, "profiles", "ransac_flop_count.json")))
+    solve_flop = counts["solve_fp64_per_hyp"]["flop"]
+    score_flop = counts["score_fp64_per_hyp"]["flop"] / counts["n_points"] * n_points \
+        + 5.0 * n_points
+    total = problems * hyps
+    round_hyps = min(total, 256 * 128)          # one GPU-full of solves per launch
+    n_rounds = math.ceil(total / round_hyps)
+    last_hyps = total - (n_rounds - 1) * round_hyps
+    # average duration of the solve launches of a step (first and last round measured)
+    solve_ms = float(np.mean(first)) if n_rounds == 1 else \
+        (float(np.mean(first)) * (n_rounds - 1) + float(np.mean(last))) / n_rounds
+    hyps_per_launch = total / n_rounds
+    achieved = hyps_per_launch * solve_flop / (solve_ms * 1e-3)
+    peak = 2.0 * fma.value
+    score_ms = float(np.mean(score))
+    return {
+        "bound": "fp64 valu",
+        "kernel": "ransac_solve_kernel<32>",
+        "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+        "frac": achieved / peak,
+        "frac_of_mul_add_rate": achieved / mix.value,
+        "traffic": None,
+        "kernel_ms": solve_ms,
+        "first_round_kernel_ms": float(np.mean(first)),
+        "last_round_kernel_ms": float(np.mean(last)),
+        "hypotheses_per_launch": hyps_per_launch,
+        "launches_per_step": n_rounds,
+        "work_per_launch": f"{hyps_per_launch:.0f} five-point EPnP solves x {solve_flop:.0f} fp64 "
+                           f"operations each (exact count of the sequential solve on this "
+                           f"workload's samples, profiles/ransac_flop_count.json; no fma: "
+                           f"the solve rounds every operation separately)",
+        "peak_source": "measured live: v_fma_f64, 8 waves/SIMD on every CU, 2 FLOP per lane-op",
+        "mul_add_rate_TFLOPs": mix.value / 1e12,
+        "mul_add_rate_note": "the ceiling of code without fma (v_mul_f64 + v_add_f64, one FLOP "
+                             "each), measured the same way",
+        "score_kernel": {
+            "kernel": "ransac_score_kernel", "kernel_ms": score_ms,
+            "hypotheses": last_hyps,
+            "flop_per_hypothesis": score_flop,
+            "achieved_TFLOPs": last_hyps * score_flop / (score_ms * 1e-3) / 1e12,
+            "frac_of_fp64_peak": last_hyps * score_flop / (score_ms * 1e-3) / peak,
+            "bytes_per_hypothesis": 20 * n_points,
+            "what": f"{n_points} reprojections per hypothesis: 25 fp64 + 5 fp32 operations and "
+                    f"20 bytes of correspondence each"},
+    }
 
 
 def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
@@ -97,24 +239,13 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
     torch.cuda.synchronize()
     single_ms = (time.perf_counter() - t0) / 5 * 1e3
 
-    step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.ransac_steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        el = all_reduce_max(el, torch, dist, dev, args.dist_backend)
+    el, r_steps = timed_region(step, args.ransac_steps, 2, args.min_seconds / 2,
+                               args.min_warmup_seconds, torch, dist, dev, world, args.dist_backend)
     res = {
-        "value": float(H) * P * world * args.ransac_steps / el,
+        "value": float(H) * P * world * r_steps / el,
         "unit": "hypotheses/s",
-        "ms_per_step": el / args.ransac_steps * 1e3,
+        "steps": r_steps,
+        "ms_per_step": el / r_steps * 1e3,
         "single_problem_ms": single_ms,
         "single_problem_hyps_per_s": H / (single_ms * 1e-3),
         "config": {"workload": f"{H} EPnP hypotheses (5-point samples, fp64) each scored on {n} "
@@ -123,6 +254,8 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
                    "n_hyp": H, "n_points": n, "problems_per_step": P},
         "dtype": "f64 solve, f32 reprojection error",
     }
+    if rank == 0:
+        res["roofline"] = ransac_roofline(args, torch, lib, _lib, step, P, H, n)
     if rank == 0:
         # whole solvePnPRansac calls (sampling, adaptive budget, inlier list and refit) from host
         # buffers: a batch of frames of the reference's size in ONE call, and one frame per call
@@ -170,8 +303,101 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
     return res
 
 
+def bench_train_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr):
+    """The train-sharded form of the matcher (BASELINE configs[4] scaled to the rank count):
+    every rank holds all queries and one contiguous shard of the train rows, searches its
+    shard with global indices, the per-shard k=2 candidates are all-gathered (RCCL) and
+    every rank merges them.  Weak scaling: the train set grows with the ranks."""
+    nq, ntl = args.shard_nq, args.shard_nt
+    if nq <= 0 or ntl <= 0:
+        return None
+
+    def rows(n, seed):   # device-side generator: any rank can rebuild any shard
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        return torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+
+    d_q = rows(nq, 4999)
+    d_t = rows(ntl, 5000 + rank)
+    base = rank * ntl
+    cand = torch.empty((2, nq, 2), dtype=torch.int32, device=dev)       # idx | dist of this shard
+    gathered = torch.empty((world * 2, nq, 2), dtype=torch.int32, device=dev)
+    out_i = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+    out_d = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+    keep = torch.empty(nq, dtype=torch.uint8, device=dev)
+    ratio = C.c_float(args.ratio)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def step(timed=False):
+        if timed:
+            ev[0].record()
+        _lib.check(lib.ph_knn_hamming256_dev(d_q.data_ptr(), nq, d_t.data_ptr(), ntl, 2, base,
+                                             cand[0].data_ptr(), cand[1].data_ptr(), None,
+                                             C.c_float(0.0), sptr))
+        if timed:
+            ev[1].record()
+        if world > 1:
+            if args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(gathered, cand)
+            else:   # gloo rehearsal: the exchange goes through host tensors
+                host = torch.empty(gathered.shape, dtype=torch.int32)
+                dist.all_gather_into_tensor(host, cand.cpu())
+                gathered.copy_(host)
+            src = gathered.view(world, 2, nq, 2)
+            all_i, all_d = src[:, 0].contiguous(), src[:, 1].contiguous()
+        else:
+            all_i, all_d = cand[0:1], cand[1:2]
+        if timed:
+            ev[2].record()
+        _lib.check(lib.ph_knn_merge_dev(all_i.data_ptr(), all_d.data_ptr(), world, nq, 2,
+                                        out_i.data_ptr(), out_d.data_ptr(), keep.data_ptr(), ratio,
+                                        sptr))
+        if timed:
+            ev[3].record()
+
+    el, steps = timed_region(step, args.shard_steps, 1, 0.0, 0.0, torch, dist, dev, world,
+                             args.dist_backend)
+    step(timed=True)
+    torch.cuda.synchronize()
+    res = {
+        "value": float(nq) * ntl * world * steps / el, "unit": "Hamming evals/s",
+        "steps": steps, "ms_per_step": el / steps * 1e3, "scaling": "weak",
+        "config": {"workload": f"{nq} queries (replicated) x {ntl * world} train rows in {world} "
+                               f"contiguous shard(s) of {ntl}, kNN k=2 + ratio {args.ratio} "
+                               f"(BASELINE configs[4] scaled to the rank count)",
+                   "nq": nq, "nt_per_rank": ntl, "nt_total": ntl * world,
+                   "parallelism": f"train shards x{world}, one all-gather of [2,nq,2] int32 per "
+                                  f"rank + merge" if world > 1 else "one shard (no exchange)"},
+        "search_ms": ev[0].elapsed_time(ev[1]),
+        "allgather_ms": ev[1].elapsed_time(ev[2]) if world > 1 else None,
+        "allgather_bytes_sent_per_rank": cand.numel() * 4 if world > 1 else 0,
+        "allgather_bytes_received_per_rank": cand.numel() * 4 * (world - 1),
+        "merge_ms": ev[2].elapsed_time(ev[3]),
+    }
+    if rank == 0:
+        # spot check: sampled queries against the whole train set in one unsharded call
+        pick = torch.randperm(nq, device=dev, generator=torch.Generator(device=dev).manual_seed(1))[:256]
+        full = torch.cat([d_t] + [rows(ntl, 5000 + r) for r in range(1, world)])
+        sq = d_q[pick].contiguous()
+        ci = torch.empty((256, 2), dtype=torch.int32, device=dev)
+        cd = torch.empty((256, 2), dtype=torch.int32, device=dev)
+        ck = torch.empty(256, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(lib.ph_knn_hamming256_dev(sq.data_ptr(), 256, full.data_ptr(), full.shape[0], 2,
+                                             0, ci.data_ptr(), cd.data_ptr(), ck.data_ptr(), ratio,
+                                             sptr))
+        torch.cuda.synchronize()
+        res["sampled_rows_equal_unsharded_call"] = bool(
+            torch.equal(out_i[pick], ci) and torch.equal(out_d[pick], cd)
+            and torch.equal(keep[pick], ck))
+        del full
+    return res
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -241,24 +467,14 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        elapsed = all_reduce_max(elapsed, torch, dist, dev, args.dist_backend)
+    elapsed, steps_run = timed_region(step, args.steps, args.warmup, args.min_seconds,
+                                      args.min_warmup_seconds, torch, dist, dev, world,
+                                      args.dist_backend)
 
     evals_per_step_all = float(nq) * nt * F * world
-    value = evals_per_step_all * args.steps / elapsed
+    value = evals_per_step_all * steps_run / elapsed
 
+    sharded = bench_train_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr)
     ransac = bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr)
 
     out = None
@@ -326,7 +542,7 @@ def main():
             return (time.perf_counter() - p0) / n
 
         # the same frames as one call each (outside the timed region above)
-        pc_steps = max(5, min(args.steps, 30))
+        pc_steps = max(5, min(steps_run, 30))
         per_call_s = timed(step_per_call, pc_steps)
         per_call = {"value": float(nq) * nt * F / per_call_s, "unit": "Hamming evals/s",
                     "us_per_frame": per_call_s / F * 1e6, "steps": pc_steps,
@@ -443,9 +659,11 @@ def main():
             "value": value,
             "unit": "Hamming evals/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps_run,
+            "steps_requested": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "timed_region_s": elapsed,
+            "ms_per_step": elapsed / steps_run * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -458,7 +676,8 @@ def main():
                 "nq": nq, "nt": nt, "k": 2, "frames_per_step": F,
                 "parallelism": f"frames x{world} (no collective)",
             },
-            "us_per_frame": elapsed / args.steps / F * 1e6,
+            "us_per_frame": elapsed / steps_run / F * 1e6,
+            "train_sharded": sharded,
             "per_call": per_call,
             "popcount_kernel": popcount,
             "roofline": roofline,

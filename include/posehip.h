@@ -211,6 +211,20 @@ ph_status ph_match_crosscheck_hamming256_dev(const void *d_query, int64_t nq, co
                                              int64_t nt, int32_t *d_out_idx, int32_t *d_out_dist,
                                              void *stream);
 
+/* The cross-check matcher when the train set is sharded over GPUs (no counterpart in the
+ * reference, which is single-process; the arithmetic is that of
+ * src/orb_feature_matching/matcher.py:18,21).  Every train row's nearest query is found
+ * among ALL queries, so that pass is local to the shard that owns the row; this call
+ * returns, per query, the best (distance, train index) among the rows of THIS shard that
+ * chose it, with train_index_base added to the index (PH_NO_MATCH_* where no row of the
+ * shard chose the query).  The cross-check result over the whole train set is the
+ * per-query minimum by (distance, global index) over the shards: all-gather the lists and
+ * fold them with ph_knn_merge_dev(k = 1). */
+ph_status ph_match_crosscheck_hamming256_shard_dev(const void *d_query, int64_t nq,
+                                                   const void *d_train_shard, int64_t nt,
+                                                   int32_t train_index_base, int32_t *d_out_idx,
+                                                   int32_t *d_out_dist, void *stream);
+
 /* ---- RANSAC-EPnP pose ------------------------------------------------------- */
 /* Replaces cv::solvePnPRansac(obj, img, K, noArray(), rvec, tvec, false,
  * iterationsCount, reprojectionError, confidence, inliers, SOLVEPNP_EPNP), the

@@ -76,9 +76,11 @@ hipError_t knn_merge_shards_launch(const int32_t *d_cand_idx, const int32_t *d_c
                                    int32_t *d_out_dist, uint8_t *d_keep, float ratio,
                                    hipStream_t stream);
 
+// index_base is added to every emitted train index (a shard of a larger train set).
 hipError_t crosscheck_resolve_launch(const int32_t *d_tidx, const int32_t *d_tdist, int64_t nt,
                                      int64_t nq, unsigned long long *d_best, int32_t *d_out_idx,
-                                     int32_t *d_out_dist, hipStream_t stream);
+                                     int32_t *d_out_dist, hipStream_t stream,
+                                     int32_t index_base = 0);
 
 // The same for a batch of frames: d_tidx / d_tdist indexed by train row of the whole
 // buffer (frame-local query indices), outputs by query row (frame-local train indices);

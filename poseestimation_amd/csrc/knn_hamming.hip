@@ -477,14 +477,14 @@ __global__ __launch_bounds__(256) void cc_scatter_kernel(const int32_t *__restri
 }
 
 __global__ __launch_bounds__(256) void cc_finalize_kernel(
-    const unsigned long long *__restrict__ best, int64_t nq, int32_t *__restrict__ out_idx,
-    int32_t *__restrict__ out_dist)
+    const unsigned long long *__restrict__ best, int64_t nq, int32_t index_base,
+    int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nq)
         return;
     const unsigned long long b = best[i];
-    out_idx[i] = b == ~0ull ? -1 : (int32_t)(uint32_t)b;
+    out_idx[i] = b == ~0ull ? -1 : (int32_t)(uint32_t)b + index_base;
     out_dist[i] = b == ~0ull ? 0x7FFFFFFF : (int32_t)(b >> 32);
 }
 
@@ -770,13 +770,13 @@ hipError_t knn_merge_shards_launch(const int32_t *d_cand_idx, const int32_t *d_c
 
 hipError_t crosscheck_resolve_launch(const int32_t *d_tidx, const int32_t *d_tdist, int64_t nt,
                                      int64_t nq, unsigned long long *d_best, int32_t *d_out_idx,
-                                     int32_t *d_out_dist, hipStream_t stream)
+                                     int32_t *d_out_dist, hipStream_t stream, int32_t index_base)
 {
     cc_init_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, stream>>>(d_best, nq);
     cc_scatter_kernel<<<(unsigned)((nt + 255) / 256), 256, 0, stream>>>(d_tidx, d_tdist, nt,
                                                                          d_best);
-    cc_finalize_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, stream>>>(d_best, nq, d_out_idx,
-                                                                          d_out_dist);
+    cc_finalize_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, stream>>>(d_best, nq, index_base,
+                                                                          d_out_idx, d_out_dist);
     return hipGetLastError();
 }
 
@@ -795,7 +795,7 @@ hipError_t crosscheck_resolve_frames_launch(const int32_t *d_tidx, const int32_t
         cc_scatter_frames_kernel<<<dim3((unsigned)((max_nt + 255) / 256), (unsigned)n_frames), 256,
                                    0, stream>>>(d_tidx, d_tdist, d_q_off, d_t_off, d_best);
     cc_finalize_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, stream>>>(
-        d_best + row_begin, rows, d_out_idx + row_begin, d_out_dist + row_begin);
+        d_best + row_begin, rows, 0, d_out_idx + row_begin, d_out_dist + row_begin);
     return hipGetLastError();
 }
 

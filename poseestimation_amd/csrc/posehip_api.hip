@@ -301,7 +301,7 @@ ph_status knn_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t n
 }
 
 ph_status crosscheck_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t nt,
-                                int32_t *d_idx, int32_t *d_dist, hipStream_t st)
+                                int32_t *d_idx, int32_t *d_dist, hipStream_t st, int32_t base = 0)
 {
     if (nq == 0)
         return PH_OK;
@@ -324,7 +324,7 @@ ph_status crosscheck_dev_locked(const void *d_q, int64_t nq, const void *d_t, in
         return s;
     PH_HIP(crosscheck_resolve_launch((const int32_t *)g_ctx.tmp_i.p, (const int32_t *)g_ctx.tmp_d.p,
                                      nt, nq, (unsigned long long *)g_ctx.best.p, d_idx, d_dist,
-                                     st));
+                                     st, base));
     return PH_OK;
 }
 
@@ -1127,6 +1127,29 @@ ph_status ph_match_crosscheck_hamming256_dev(const void *d_query, int64_t nq, co
         return fail(PH_ERR_INVALID_ARG, "null output pointer");
     return crosscheck_dev_locked(d_query, nq, d_train, nt, d_out_idx, d_out_dist,
                                  pick_stream(stream));
+}
+
+ph_status ph_match_crosscheck_hamming256_shard_dev(const void *d_query, int64_t nq,
+                                                   const void *d_train_shard, int64_t nt,
+                                                   int32_t train_index_base, int32_t *d_out_idx,
+                                                   int32_t *d_out_dist, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if ((s = check_rows(d_query, nq, "query")) != PH_OK)
+        return s;
+    if ((s = check_rows(d_train_shard, nt, "train")) != PH_OK)
+        return s;
+    if (nq > 0 && (!d_out_idx || !d_out_dist))
+        return fail(PH_ERR_INVALID_ARG, "null output pointer");
+    if (train_index_base < 0)
+        return fail(PH_ERR_INVALID_ARG, "negative train_index_base");
+    if (nt > 0 && (int64_t)train_index_base + nt - 1 > 0x7FFFFFFF)
+        return fail(PH_ERR_TOO_LARGE, "train_index_base + nt exceeds the 32-bit index range");
+    return crosscheck_dev_locked(d_query, nq, d_train_shard, nt, d_out_idx, d_out_dist,
+                                 pick_stream(stream), train_index_base);
 }
 
 ph_status ph_knn_hamming256(const uint8_t *query, int nq, size_t q_step, const uint8_t *train,

@@ -1,7 +1,7 @@
 """One-process-per-GPU partitioning of the matcher (torch.distributed; backend
 "nccl" is RCCL on ROCm).
 
-Two modes, neither of which exists in the reference (it is single-process):
+Three modes, none of which exists in the reference (it is single-process):
 
 frame batch   independent frames against one replicated train set: frames are
               dealt to ranks in contiguous blocks and nothing is exchanged.
@@ -12,6 +12,9 @@ train shards  one large train set split into contiguous row ranges, one per
               gathered in rank order = ascending index order, and the merge key is
               (distance, global index), so OpenCV's lowest-index tie-break holds
               across shards.
+cross-check   the same sharding for the cross-check matcher: the swapped 1-NN pass is
+              local to the shard that owns the train row, the per-query winners are
+              all-gathered and folded the same way (match_crosscheck_train_sharded).
 """
 import ctypes as C
 
@@ -94,6 +97,41 @@ def knn_train_sharded(d_query, d_train_shard, shard_base, k, ratio=None, group=N
                                     keep.data_ptr() if keep is not None else None,
                                     float(ratio) if ratio is not None else 0.0, sp))
     return out_idx, out_dst, keep
+
+
+def match_crosscheck_train_sharded(d_query, d_train_shard, shard_base, group=None):
+    """Cross-check match (BFMatcher(NORM_HAMMING, crossCheck=True).match) of all queries
+    against a train set sharded over the ranks of `group`.
+
+    OpenCV's cross-check finds every TRAIN row's nearest query and then, per query, keeps
+    the best (distance, train index) among the train rows that chose it.  With the
+    queries replicated the first step is local to the shard that owns the train row; the
+    second is a per-query minimum over the shards: every rank emits its shard's winners
+    with GLOBAL train indices, the lists are all-gathered (the one exchange step) and
+    folded by (distance, global index), which keeps the lowest-index rule across shards.
+
+    d_query: uint8 [nq, 32] (the same on every rank); d_train_shard: uint8 [nt_local, 32],
+    rows [shard_base, shard_base + nt_local) of the global train set.  Returns (idx [nq],
+    dist [nq]) GPU tensors, identical on every rank: the matched global train row or -1.
+    """
+    lib = _lib.load()
+    nq, nt = d_query.shape[0], d_train_shard.shape[0]
+    dev = d_query.device
+    idx = torch.empty((nq, 1), dtype=torch.int32, device=dev)
+    dst = torch.empty((nq, 1), dtype=torch.int32, device=dev)
+    sp = _stream_ptr()
+    if sp is None:
+        raise RuntimeError("run under `with torch.cuda.stream(torch.cuda.Stream())`: torch's "
+                           "default stream has no handle to pass through the C ABI")
+    _lib.check(lib.ph_match_crosscheck_hamming256_shard_dev(
+        d_query.data_ptr(), nq, d_train_shard.data_ptr() if nt else None, nt, int(shard_base),
+        idx.data_ptr(), dst.data_ptr(), sp))
+    all_idx, all_dst = allgather_candidates(idx, dst, group)
+    out_idx = torch.empty_like(idx)
+    out_dst = torch.empty_like(dst)
+    _lib.check(lib.ph_knn_merge_dev(all_idx.data_ptr(), all_dst.data_ptr(), all_idx.shape[0], nq,
+                                    1, out_idx.data_ptr(), out_dst.data_ptr(), None, 0.0, sp))
+    return out_idx.view(nq), out_dst.view(nq)
 
 
 def knn_frames(d_query, q_offsets, d_train, t_offsets, k, ratio=None):

@@ -80,3 +80,41 @@ def test_train_sharded_allgather_world2(tie_stress):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, 150, 401, 2, tie_stress, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _crosscheck_worker(rank, world, port, nq, nt, tie_stress, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if tie_stress:
+            q, t = datagen.codebook_descriptors(nq, 7, words=8), datagen.codebook_descriptors(nt, 8, words=8)
+        else:
+            q = datagen.random_descriptors(nq, 7)
+            t = np.concatenate([datagen.perturbed_copy(q, 9)[:nt // 2],
+                                datagen.random_descriptors(nt - nt // 2, 10)])
+        lo, hi = block_bounds(nt, world, rank)
+        # the shard's winners: cross-check of all queries against the shard's rows alone
+        idx = np.full((nq, 1), -1, np.int32)
+        dst = np.full((nq, 1), 2147483647, np.int32)
+        for qi, ti, _, d in orc.match(q, t[lo:hi], cross_check=True):
+            idx[qi, 0], dst[qi, 0] = ti + lo, int(d)
+        ai, ad = allgather_candidates(torch.from_numpy(idx), torch.from_numpy(dst))
+        mi, md = _merge_top2(ai.numpy(), ad.numpy(), 1)
+        got = [(qi, int(mi[qi, 0]), 0, float(md[qi, 0])) for qi in range(nq) if mi[qi, 0] >= 0]
+        ret[rank] = got == orc.match(q, t, cross_check=True) and len(got) > 0
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tie_stress", [False, True])
+def test_crosscheck_train_sharded_world2(tie_stress):
+    """Cross-check under train sharding: per-shard winners (global indices) all-gathered and
+    folded by (distance, index) equal the unsharded cross-check match."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_crosscheck_worker, args=(world, port, 180, 333, tie_stress, ret), nprocs=world,
+             join=True)
+    assert dict(ret) == {0: True, 1: True}

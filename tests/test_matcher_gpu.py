@@ -283,6 +283,72 @@ def test_shard_merge(posehip, n_shards, k):
         assert np.nonzero(keep.cpu().numpy())[0].tolist() == kept
 
 
+@pytest.mark.parametrize("n_shards,tie_stress", [(2, False), (3, True), (8, False), (8, True)])
+def test_crosscheck_shards(posehip, n_shards, tie_stress):
+    """Cross-check match with the train set in contiguous shards: every shard's winners
+    (ph_match_crosscheck_hamming256_shard_dev, global indices), folded by
+    ph_knn_merge_dev(k=1) as after the all-gather of a train-sharded job, equal the
+    unsharded cross-check match of the oracle."""
+    import torch
+    from poseestimation_amd.distributed import block_bounds
+    nq, nt = 1500, 2600
+    if tie_stress:
+        q = datagen.codebook_descriptors(nq, 55, words=16)
+        t = datagen.codebook_descriptors(nt, 56, words=16)
+    else:
+        q = datagen.random_descriptors(nq, 55)
+        t = np.concatenate([datagen.perturbed_copy(q, 57)[:1300], datagen.random_descriptors(1300, 58)])
+    d_q, d_t = _dev(q), _dev(t)
+    ci, cd = [], []
+    for s in range(n_shards):
+        lo, hi = block_bounds(nt, n_shards, s)
+        i = torch.full((nq, 1), 777, dtype=torch.int32, device="cuda:0")
+        d = torch.full((nq, 1), 777, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        posehip.check(posehip.load().ph_match_crosscheck_hamming256_shard_dev(
+            d_q.data_ptr(), nq, d_t[lo:hi].data_ptr(), hi - lo, lo, i.data_ptr(), d.data_ptr(), None))
+        posehip.check(posehip.load().ph_stream_synchronize(None))
+        ci.append(i)
+        cd.append(d)
+        loc = i.cpu().numpy().ravel()
+        assert ((loc == -1) | ((loc >= lo) & (loc < hi))).all()
+    all_i, all_d = torch.stack(ci).contiguous(), torch.stack(cd).contiguous()
+    out_i = torch.empty((nq, 1), dtype=torch.int32, device="cuda:0")
+    out_d = torch.empty((nq, 1), dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    posehip.check(posehip.load().ph_knn_merge_dev(all_i.data_ptr(), all_d.data_ptr(), n_shards, nq,
+                                                  1, out_i.data_ptr(), out_d.data_ptr(), None, 0.0,
+                                                  None))
+    posehip.check(posehip.load().ph_stream_synchronize(None))
+    idx, dist = out_i.cpu().numpy().ravel(), out_d.cpu().numpy().ravel()
+    got = [(int(i), int(idx[i]), 0, float(dist[i])) for i in range(nq) if idx[i] >= 0]
+    want = orc.match(q, t, cross_check=True)
+    assert got == want and len(got) > 0
+
+
+def test_crosscheck_train_sharded_world1(posehip):
+    """match_crosscheck_train_sharded end to end in a one-rank group on the GPU."""
+    import torch
+    import torch.distributed as dist
+    from poseestimation_amd.distributed import match_crosscheck_train_sharded
+    q = datagen.random_descriptors(900, 63)
+    t = datagen.perturbed_copy(q, 64)[:700]
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29618", rank=0, world_size=1)
+        created = True
+    try:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            idx, dst = match_crosscheck_train_sharded(_dev(q), _dev(t), 0)
+            torch.cuda.current_stream().synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    idx, dst = idx.cpu().numpy(), dst.cpu().numpy()
+    got = [(int(i), int(idx[i]), 0, float(dst[i])) for i in range(900) if idx[i] >= 0]
+    assert got == orc.match(q, t, cross_check=True)
+
+
 def test_train_sharded_world1(posehip):
     """knn_train_sharded end to end in a one-rank group on the GPU."""
     import torch
