@@ -1714,11 +1714,10 @@ __device__ void rodrigues_vec_to_mat(const double r[3], double R[9])
 
 // projectPoints (zero distortion) + float squared error + threshold test of
 // PnPRansacCallback::computeError / findInliers for point i.
-__device__ inline bool is_inlier(const float *obj, const float *img, int64_t i, const double *R,
-                                 const double *t, double fx, double fy, double cx, double cy,
-                                 float thr2)
+__device__ __forceinline__ bool inlier_of(double X, double Y, double Z, float u, float v,
+                                          const double *R, const double *t, double fx, double fy,
+                                          double cx, double cy, float thr2)
 {
-    const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
     double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
     double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
     double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
@@ -1726,9 +1725,17 @@ __device__ inline bool is_inlier(const float *obj, const float *img, int64_t i, 
     x *= z;
     y *= z;
     const float px = (float)(x * fx + cx), py = (float)(y * fy + cy);
-    const float dx = img[2 * i] - px, dy = img[2 * i + 1] - py;
+    const float dx = u - px, dy = v - py;
     const float err = dx * dx + dy * dy;
     return err <= thr2;
+}
+
+__device__ inline bool is_inlier(const float *obj, const float *img, int64_t i, const double *R,
+                                 const double *t, double fx, double fy, double cx, double cy,
+                                 float thr2)
+{
+    return inlier_of(obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], img[2 * i], img[2 * i + 1], R, t,
+                     fx, fy, cx, cy, thr2);
 }
 
 __device__ inline Points make_points(const float *obj, const float *img, const int32_t *idx, int n,
@@ -1846,40 +1853,103 @@ __global__ __launch_bounds__(64 * 3) void ransac_solve3_kernel(
     m[3] = t[0]; m[4] = t[1]; m[5] = t[2];
 }
 
-// Scoring kernel: one wavefront per hypothesis (4 per workgroup); lanes stride
-// over the n correspondences, inlier count by ballot + popcount.
-__global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restrict__ obj,
-                                                           const float *__restrict__ img, int n,
-                                                           CameraK K,
-                                                           const double *__restrict__ models,
-                                                           const int32_t *__restrict__ begins,
-                                                           const int32_t *__restrict__ ends,
-                                                           int hyp_per_problem, int h0, int n_hyp,
-                                                           float thr2, int32_t *__restrict__ counts)
+// A wave-uniform double moved to scalar registers (every lane holds the same value).
+__device__ __forceinline__ double to_sgpr(double v)
+{
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// Scoring kernel.  Every wave scores SCORE_HPW consecutive hypotheses of one problem, two
+// at a time: a correspondence is loaded (from L2: a problem's rows are read by thousands of
+// waves) and converted to double once for two models, whose rotations sit in scalar
+// registers (they are wave-uniform), and the two reprojection chains interleave.  Lanes
+// stride over the rows; inlier count by ballot + popcount.  Arithmetic per row and model:
+// inlier_of(), the same operations in the same order as the sequential statement.
+// (Staging the rows in LDS -- 40 KB per workgroup for 2000 rows -- was measured: the kernel is
+// bound by its fp64 instruction count, not by its loads, so alone it runs no faster, and
+// the LDS it takes keeps solve workgroups of the next round off the CU: the step got 8 %
+// slower.)
+constexpr int SCORE_WAVES = 4;
+constexpr int SCORE_HPW = 2;
+constexpr int SCORE_HPB = SCORE_WAVES * SCORE_HPW;
+
+__global__ __launch_bounds__(64 * SCORE_WAVES) void ransac_score_kernel(
+    const float *__restrict__ obj, const float *__restrict__ img, int n, CameraK K,
+    const double *__restrict__ models, const int32_t *__restrict__ begins,
+    const int32_t *__restrict__ ends, int hyp_per_problem, int h0, int n_hyp, float thr2,
+    int32_t *__restrict__ counts)
 {
     const int lane = threadIdx.x & 63;
-    const int h = h0 + blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (h >= n_hyp)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ha = h0 + (blockIdx.x * SCORE_WAVES + wave) * SCORE_HPW, hb = ha + 1;
+    if (ha >= n_hyp)
         return;
-    if (begins) {
-        const int p = h / hyp_per_problem;
-        const int64_t row0 = begins[p];
-        n = ends[p] - begins[p];
-        obj += 3 * row0;
-        img += 2 * row0;
+    const bool vb = hb < n_hyp; // (an odd tail: the second chain repeats the first)
+    const double fx = K.fx, fy = K.fy, cx = K.cx, cy = K.cy;
+    double Ra[9], ta[3], Rb[9], tb[3];
+    {
+        const double *ma = models + (int64_t)ha * 6;
+        const double *mb = models + (int64_t)(vb ? hb : ha) * 6;
+        const double ra[3] = {ma[0], ma[1], ma[2]}, rb[3] = {mb[0], mb[1], mb[2]};
+        rodrigues_vec_to_mat(ra, Ra);
+        rodrigues_vec_to_mat(rb, Rb);
+#pragma unroll
+        for (int e = 0; e < 9; e++) {
+            Ra[e] = to_sgpr(Ra[e]);
+            Rb[e] = to_sgpr(Rb[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 3; e++) { // (scalar registers are spent on R: t stays in vector ones)
+            ta[e] = ma[3 + e];
+            tb[e] = mb[3 + e];
+        }
     }
-    const double *m = models + (int64_t)h * 6;
-    const double r[3] = {m[0], m[1], m[2]}, tv[3] = {m[3], m[4], m[5]};
-    double Rm[9];
-    rodrigues_vec_to_mat(r, Rm);
-    int good = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const bool f = i < n && is_inlier(obj, img, i, Rm, tv, K.fx, K.fy, K.cx, K.cy, thr2);
-        good += __builtin_popcountll(__ballot(f));
+    // the two hypotheses may belong to different problems (hyp_per_problem odd)
+    const int pa = begins ? ha / hyp_per_problem : 0, pb = begins && vb ? hb / hyp_per_problem : pa;
+    int ga = 0, gb = 0;
+    if (pa == pb) {
+        const int64_t row0 = begins ? begins[pa] : 0;
+        const int rows = begins ? ends[pa] - begins[pa] : n;
+        const float *o = obj + 3 * row0, *im = img + 2 * row0;
+        for (int base = 0; base < rows; base += 64) {
+            const int i = base + lane;
+            const bool in = i < rows;
+            const int ii = in ? i : 0;
+            const double X = o[3 * ii], Y = o[3 * ii + 1], Z = o[3 * ii + 2];
+            const float u = im[2 * ii], v = im[2 * ii + 1];
+            // (no short circuit: both chains run on every lane and interleave)
+            const bool fa = inlier_of(X, Y, Z, u, v, Ra, ta, fx, fy, cx, cy, thr2) & in;
+            const bool fb = inlier_of(X, Y, Z, u, v, Rb, tb, fx, fy, cx, cy, thr2) & in;
+            ga += __builtin_popcountll(__ballot(fa));
+            gb += __builtin_popcountll(__ballot(fb));
+        }
+    } else {
+        for (int side = 0; side < 2; side++) {
+            const int p = side ? pb : pa;
+            const int64_t row0 = begins[p];
+            const int rows = ends[p] - begins[p];
+            int g = 0;
+            for (int base = 0; base < rows; base += 64) {
+                const int i = base + lane;
+                const bool f = i < rows && is_inlier(obj + 3 * row0, img + 2 * row0, i,
+                                                     side ? Rb : Ra, side ? tb : ta, fx, fy, cx,
+                                                     cy, thr2);
+                g += __builtin_popcountll(__ballot(f));
+            }
+            if (side)
+                gb = g;
+            else
+                ga = g;
+        }
     }
-    if (lane == 0)
-        counts[h] = good;
+    if (lane == 0) {
+        counts[ha] = ga;
+        if (vb)
+            counts[hb] = gb;
+    }
 }
 
 // EPnP on the correspondences P by a workgroup of THREE waves, one per candidate (beta
@@ -2127,9 +2197,9 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
                 return e;
             ss = overlap->side;
         }
-        ransac_score_kernel<<<(h1 - h0 + 3) / 4, 256, 0, ss>>>(d_obj, d_img, n, K, d_models,
-                                                               d_begins, d_ends, hyp_per_problem,
-                                                               h0, h1, thr2, d_counts);
+        ransac_score_kernel<<<(h1 - h0 + SCORE_HPB - 1) / SCORE_HPB, 64 * SCORE_WAVES, 0, ss>>>(
+            d_obj, d_img, n, K, d_models, d_begins, d_ends, hyp_per_problem, h0, h1, thr2,
+            d_counts);
         if ((e = hipGetLastError()) != hipSuccess)
             return e;
         if (events && last && (e = hipEventRecord(events[4], stream)) != hipSuccess)
