@@ -4,8 +4,10 @@
 // current frame against them (:344), filters by distance (:345-356), and -- on
 // its EPnP branch -- feeds 2D-3D pairs to solvePnPRansac.  This program does the
 // same with synthetic frames (ORB detection and the OpenGL renderer stay on the
-// host in the reference and are not part of this library), and prints a digest
-// that tests/test_cpp_shim_gpu.py compares with the CPU oracle.
+// host in the reference and are not part of this library).  With a file name as its
+// argument it also writes its inputs and results there (raw little-endian arrays, in the
+// order of the dump() calls below); tests/test_cpp_shim.py reads that file and checks every
+// result against the CPU oracle.
 //
 // build: g++ -std=c++17 -O2 examples/cereal_box_matcher.cpp -Iinclude -Lposeestimation_amd -lposehip
 //            -Wl,-rpath,'$ORIGIN/../poseestimation_amd' -o examples/cereal_box_matcher
@@ -18,6 +20,16 @@
 
 using namespace posehip;
 
+static std::FILE *g_dump = nullptr;
+template <typename T> static void dump(const T *p, std::size_t n)
+{
+    if (g_dump) {
+        const std::int64_t count = (std::int64_t)n;
+        std::fwrite(&count, sizeof(count), 1, g_dump);
+        std::fwrite(p, sizeof(T), n, g_dump);
+    }
+}
+
 static std::vector<std::uint8_t> random_descriptors(int n, unsigned seed)
 {
     std::mt19937 rng(seed);
@@ -27,8 +39,10 @@ static std::vector<std::uint8_t> random_descriptors(int n, unsigned seed)
     return d;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1 && !(g_dump = std::fopen(argv[1], "wb")))
+        return 2;
     // matching global variables of the reference (src/cereal_box.cpp:47-53)
     std::vector<DMatch> matches, good_matches;
     auto matcher = DescriptorMatcher::create("BruteForce-Hamming");
@@ -75,6 +89,13 @@ int main()
     if (!resident_same)
         return 1;
 
+    dump(descriptors.data(), descriptors.size());
+    dump(descriptorsOld.data(), descriptorsOld.size());
+    dump(reinterpret_cast<const std::int32_t *>(matches.data()), matches.size() * 4);
+    dump(reinterpret_cast<const std::int32_t *>(good_matches.data()), good_matches.size() * 4);
+    dump(reinterpret_cast<const std::int32_t *>(cc.data()), cc.size() * 4);
+    dump(reinterpret_cast<const std::int32_t *>(ratio.data()), ratio.size() * 4);
+
     long long digest = 0;
     for (const DMatch &m : matches)
         digest = digest * 1000003 + m.queryIdx * 131 + m.trainIdx * 17 + (int)m.distance;
@@ -101,7 +122,16 @@ int main()
     }
     double rvec[3], tvec[3];
     std::vector<int> inliers;
-    const bool ok = solvePnPRansac(obj, img, K, rvec, tvec, false, 100, 8.0f, 0.99, &inliers);
+    // OpenCV's positional arguments: (obj, img, K, distCoeffs, rvec, tvec, useExtrinsicGuess,
+    // iterationsCount, reprojectionError, confidence, inliers, flags)
+    const bool ok = solvePnPRansac(obj, img, K, noArray(), rvec, tvec, false, 100, 8.0f, 0.99, inliers,
+                                   SOLVEPNP_EPNP);
+    dump(&obj[0].x, obj.size() * 3);
+    dump(&img[0].x, img.size() * 2);
+    dump(K, 9);
+    dump(rvec, 3);
+    dump(tvec, 3);
+    dump(inliers.data(), inliers.size());
     std::printf("pnp ok %d inliers %zu rvec %.6f %.6f %.6f tvec %.6f %.6f %.6f\n", (int)ok, inliers.size(), rvec[0],
                 rvec[1], rvec[2], tvec[0], tvec[1], tvec[2]);
     // the same frame three times as one batched call: every result equals the single call
@@ -112,5 +142,7 @@ int main()
                std::memcmp(r.tvec, tvec, sizeof(tvec)) == 0;
     std::printf("pnp batch of 3 identical to the single call: %d\n", (int)same);
     ph_shutdown();
+    if (g_dump)
+        std::fclose(g_dump);
     return ok && same && inliers.size() >= 300 && inliers.size() <= 305 ? 0 : 1;
 }

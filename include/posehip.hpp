@@ -9,8 +9,9 @@
 //   EPnP branch (docs/index.md:75,120)  solvePnPRansac(obj, img, K, dist, rvec, tvec, false, iters, err, conf, inliers, SOLVEPNP_EPNP)
 //
 // The header needs no OpenCV.  Define POSEHIP_WITH_OPENCV before including it
-// (with <opencv2/core.hpp> on the include path) to get overloads that take
-// cv::Mat / std::vector<cv::DMatch> directly.  Errors: the C ABI never throws;
+// (with <opencv2/core.hpp> on the include path) to get overloads on OpenCV's own types:
+// match / knnMatch taking cv::Mat and std::vector<cv::DMatch>, and solvePnPRansac on
+// cv::InputArray / cv::OutputArray.  Errors: the C ABI never throws;
 // this shim converts a non-zero status into posehip::Error (the reference lets
 // cv::Exception propagate the same way).
 #ifndef POSEHIP_HPP
@@ -131,6 +132,35 @@ class BFMatcher {
     }
 
     bool isCrossCheck() const { return crossCheck_; }
+
+#ifdef POSEHIP_WITH_OPENCV
+    // The same two calls on OpenCV's own match type, so that the reference's
+    // `std::vector<DMatch> matches; matcher->match(descriptors, descriptorsOld, matches);`
+    // (src/cereal_box.cpp:51,344, with `using namespace cv`) compiles unchanged: cv::Mat
+    // converts to Descriptors, and cv::DMatch has the layout of posehip::DMatch.
+    void match(const Descriptors &query, const Descriptors &train, std::vector<cv::DMatch> &matches) const
+    {
+        std::vector<DMatch> tmp;
+        match(query, train, tmp);
+        copyMatches(tmp, matches);
+    }
+    void knnMatch(const Descriptors &query, const Descriptors &train,
+                  std::vector<std::vector<cv::DMatch>> &matches, int k) const
+    {
+        std::vector<std::vector<DMatch>> tmp;
+        knnMatch(query, train, tmp, k);
+        matches.resize(tmp.size());
+        for (std::size_t i = 0; i < tmp.size(); i++)
+            copyMatches(tmp[i], matches[i]);
+    }
+    static void copyMatches(const std::vector<DMatch> &from, std::vector<cv::DMatch> &to)
+    {
+        static_assert(sizeof(cv::DMatch) == sizeof(DMatch), "cv::DMatch layout");
+        to.resize(from.size());
+        if (!from.empty())
+            std::memcpy(static_cast<void *>(to.data()), from.data(), from.size() * sizeof(DMatch));
+    }
+#endif
 
     // ---- the train collection of cv::DescriptorMatcher: add() one descriptor set per
     // train image, train() uploads their concatenation to the GPU once, and
@@ -262,35 +292,79 @@ struct Point2f {
     float x, y;
 };
 
-// cv::solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs = none,
-// rvec, tvec, useExtrinsicGuess = false, iterationsCount = 100,
-// reprojectionError = 8.0, confidence = 0.99, inliers, flags = SOLVEPNP_EPNP).
-// cameraMatrix: row-major 3 x 3.  rvec / tvec: 3 doubles each.
+// Stand-ins for the optional arrays of cv::solvePnPRansac.  distCoeffs: noArray(), an
+// empty vector or all zeros (the reference renders with an ideal pinhole,
+// src/cereal_box.cpp:222); anything else is refused, lens distortion being outside this
+// path.  inliers: noArray() or a std::vector<int> to fill.
+struct NoArray {};
+inline NoArray noArray() { return {}; }
+struct DistCoeffs {
+    bool zero = true;
+    DistCoeffs() = default;
+    DistCoeffs(NoArray) {}        // NOLINT: implicit, like cv::InputArray
+    DistCoeffs(std::nullptr_t) {} // NOLINT
+    template <typename T> DistCoeffs(const std::vector<T> &v) // NOLINT
+    {
+        for (const T &c : v)
+            zero = zero && c == T(0);
+    }
+};
+struct InliersOut {
+    std::vector<int> *v = nullptr;
+    InliersOut(NoArray) {}                    // NOLINT: implicit, like cv::OutputArray
+    InliersOut(std::nullptr_t) {}             // NOLINT
+    InliersOut(std::vector<int> &x) : v(&x) {} // NOLINT
+    InliersOut(std::vector<int> *x) : v(x) {}  // NOLINT
+};
+
+// cv::solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec, tvec,
+// useExtrinsicGuess = false, iterationsCount = 100, reprojectionError = 8.0,
+// confidence = 0.99, inliers = noArray(), flags): OpenCV's positional signature, the call
+// of the reference's EPnP branch (docs/index.md:75,120; TODO at src/cereal_box.cpp:292-295).
+// cameraMatrix: row-major 3 x 3.  rvec / tvec: 3 doubles each.  Only SOLVEPNP_EPNP is
+// implemented, so it is the default here (OpenCV's default is SOLVEPNP_ITERATIVE; the
+// reference passes SOLVEPNP_EPNP).  Fewer than 5 correspondences: posehip::Error, where
+// OpenCV throws cv::Exception (or takes P3P at exactly 4).
 inline bool solvePnPRansac(const std::vector<Point3f> &objectPoints, const std::vector<Point2f> &imagePoints,
-                           const double cameraMatrix[9], double rvec[3], double tvec[3],
-                           bool useExtrinsicGuess = false, int iterationsCount = 100,
+                           const double cameraMatrix[9], const DistCoeffs &distCoeffs, double rvec[3],
+                           double tvec[3], bool useExtrinsicGuess = false, int iterationsCount = 100,
                            float reprojectionError = 8.0f, double confidence = 0.99,
-                           std::vector<int> *inliers = nullptr, int flags = SOLVEPNP_EPNP)
+                           InliersOut inliers = noArray(), int flags = SOLVEPNP_EPNP)
 {
     if (flags != SOLVEPNP_EPNP || useExtrinsicGuess)
         throw Error(PH_ERR_INVALID_ARG, "only SOLVEPNP_EPNP without an extrinsic guess is implemented");
+    if (!distCoeffs.zero)
+        throw Error(PH_ERR_INVALID_ARG, "lens distortion is not implemented (pass noArray() or zeros)");
     if (objectPoints.size() != imagePoints.size())
         throw Error(PH_ERR_INVALID_ARG, "objectPoints and imagePoints differ in length");
+    if (objectPoints.size() < 5)
+        throw Error(PH_ERR_INVALID_ARG, "RANSAC-EPnP needs at least 5 correspondences");
     if (ph_device() < 0)
         check(ph_init(0));
     const int n = (int)objectPoints.size();
     std::vector<std::int32_t> inl((std::size_t)n);
     int n_inl = 0, found = 0;
-    check(ph_solvepnp_ransac_epnp(&objectPoints[0].x, &imagePoints[0].x, n, cameraMatrix, iterationsCount,
-                                  reprojectionError, confidence, 0xFFFFFFFFFFFFFFFFull, rvec, tvec, inl.data(),
-                                  &n_inl, &found, nullptr));
-    if (inliers) {
+    check(ph_solvepnp_ransac_epnp(&objectPoints.data()->x, &imagePoints.data()->x, n, cameraMatrix,
+                                  iterationsCount, reprojectionError, confidence, 0xFFFFFFFFFFFFFFFFull, rvec,
+                                  tvec, inl.data(), &n_inl, &found, nullptr));
+    if (inliers.v) {
         if (found)
-            inliers->assign(inl.begin(), inl.begin() + n_inl);
+            inliers.v->assign(inl.begin(), inl.begin() + n_inl);
         else
-            inliers->clear();
+            inliers.v->clear();
     }
     return found != 0;
+}
+
+// The same without the distCoeffs slot (zero distortion).
+inline bool solvePnPRansac(const std::vector<Point3f> &objectPoints, const std::vector<Point2f> &imagePoints,
+                           const double cameraMatrix[9], double rvec[3], double tvec[3],
+                           bool useExtrinsicGuess = false, int iterationsCount = 100,
+                           float reprojectionError = 8.0f, double confidence = 0.99,
+                           InliersOut inliers = noArray(), int flags = SOLVEPNP_EPNP)
+{
+    return solvePnPRansac(objectPoints, imagePoints, cameraMatrix, DistCoeffs(), rvec, tvec, useExtrinsicGuess,
+                          iterationsCount, reprojectionError, confidence, inliers, flags);
 }
 
 // solvePnPRansac for a batch of frames in one call (shared camera and RANSAC
@@ -354,12 +428,63 @@ inline std::vector<PnPResult> solvePnPRansacBatch(const std::vector<std::vector<
 // Drop-in overloads on OpenCV's own types.
 inline void match(const BFMatcher &m, const cv::Mat &query, const cv::Mat &train, std::vector<cv::DMatch> &out)
 {
-    std::vector<DMatch> tmp;
-    m.match(Descriptors(query), Descriptors(train), tmp);
-    out.resize(tmp.size());
-    static_assert(sizeof(cv::DMatch) == sizeof(DMatch), "cv::DMatch layout");
-    if (!tmp.empty())
-        std::memcpy(static_cast<void *>(out.data()), tmp.data(), tmp.size() * sizeof(DMatch));
+    m.match(Descriptors(query), Descriptors(train), out);
+}
+
+// cv::solvePnPRansac on OpenCV's array types: objectPoints N x 3 (or N-vector of Point3f),
+// imagePoints N x 2 (or N-vector of Point2f), cameraMatrix 3 x 3, distCoeffs empty or
+// zeros; rvec / tvec come back as 3 x 1 CV_64F, inliers as an N x 1 CV_32S column.
+inline bool solvePnPRansac(cv::InputArray objectPoints, cv::InputArray imagePoints, cv::InputArray cameraMatrix,
+                           cv::InputArray distCoeffs, cv::OutputArray rvec, cv::OutputArray tvec,
+                           bool useExtrinsicGuess = false, int iterationsCount = 100,
+                           float reprojectionError = 8.0f, double confidence = 0.99,
+                           cv::OutputArray inliers = cv::noArray(), int flags = SOLVEPNP_EPNP)
+{
+    const cv::Mat obj_in = objectPoints.getMat(), img_in = imagePoints.getMat();
+    cv::Mat obj, img, K, dist;
+    const int n = obj_in.checkVector(3), n2 = img_in.checkVector(2);
+    if (n < 0 || n2 != n)
+        throw Error(PH_ERR_INVALID_ARG, "objectPoints must hold N 3-D points and imagePoints N 2-D points");
+    obj_in.reshape(1, n).convertTo(obj, CV_32F); // N x 3 / N x 2 float
+    img_in.reshape(1, n).convertTo(img, CV_32F);
+    cameraMatrix.getMat().convertTo(K, CV_64F);
+    if (K.rows != 3 || K.cols != 3)
+        throw Error(PH_ERR_INVALID_ARG, "cameraMatrix must be 3 x 3");
+    const double k9[9] = {K.at<double>(0, 0), K.at<double>(0, 1), K.at<double>(0, 2),
+                          K.at<double>(1, 0), K.at<double>(1, 1), K.at<double>(1, 2),
+                          K.at<double>(2, 0), K.at<double>(2, 1), K.at<double>(2, 2)};
+    std::vector<double> d;
+    if (!distCoeffs.empty()) {
+        distCoeffs.getMat().convertTo(dist, CV_64F);
+        for (int i = 0; i < (int)dist.total(); i++)
+            d.push_back(dist.reshape(1, 1).at<double>(0, i));
+    }
+    std::vector<Point3f> o((std::size_t)n);
+    std::vector<Point2f> p((std::size_t)n);
+    for (int i = 0; i < n; i++) {
+        o[(std::size_t)i] = {obj.at<float>(i, 0), obj.at<float>(i, 1), obj.at<float>(i, 2)};
+        p[(std::size_t)i] = {img.at<float>(i, 0), img.at<float>(i, 1)};
+    }
+    double r[3], t[3];
+    std::vector<int> inl;
+    const bool ok = solvePnPRansac(o, p, k9, DistCoeffs(d), r, t, useExtrinsicGuess, iterationsCount,
+                                   reprojectionError, confidence, InliersOut(inl), flags);
+    if (ok) {
+        rvec.create(3, 1, CV_64F);
+        tvec.create(3, 1, CV_64F);
+        cv::Mat rm = rvec.getMat(), tm = tvec.getMat();
+        for (int i = 0; i < 3; i++) {
+            rm.at<double>(i, 0) = r[i];
+            tm.at<double>(i, 0) = t[i];
+        }
+    }
+    if (inliers.needed()) {
+        inliers.create((int)inl.size(), 1, CV_32S);
+        cv::Mat im = inliers.getMat();
+        for (int i = 0; i < (int)inl.size(); i++)
+            im.at<int>(i, 0) = inl[(std::size_t)i];
+    }
+    return ok;
 }
 #endif
 
