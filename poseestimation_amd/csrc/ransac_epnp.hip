@@ -25,9 +25,10 @@
 // on any number of inliers in O(1) memory.
 // Where few problems are in flight (a lone small call; the refit on the inliers) a
 // problem gets a workgroup of three waves, one per candidate, each on its own LDS copy.
-// Scoring is a second kernel with ONE HYPOTHESIS PER WAVEFRONT: the 64 lanes
-// stride over the correspondences and the inlier count is reduced with
-// ballot + popcount.
+// Scoring is a second kernel with TWO HYPOTHESES PER WAVEFRONT at a time: the 64 lanes
+// stride over the correspondences, a packed-fp32 first pass with a rigorous error bound
+// settles almost every (row, model) verdict and the exact fp64 evaluation runs only for
+// the batches it cannot settle; the inlier count is reduced with ballot + popcount.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
@@ -1863,15 +1864,133 @@ __device__ __forceinline__ double to_sgpr(double v)
 }
 
 // Scoring kernel.  Every wave scores SCORE_HPW consecutive hypotheses of one problem, two
-// at a time: a correspondence is loaded (from L2: a problem's rows are read by thousands of
-// waves) and converted to double once for two models, whose rotations sit in scalar
-// registers (they are wave-uniform), and the two reprojection chains interleave.  Lanes
-// stride over the rows; inlier count by ballot + popcount.  Arithmetic per row and model:
-// inlier_of(), the same operations in the same order as the sequential statement.
-// (Staging the rows in LDS -- 40 KB per workgroup for 2000 rows -- was measured: the kernel is
-// bound by its fp64 instruction count, not by its loads, so alone it runs no faster, and
-// the LDS it takes keeps solve workgroups of the next round off the CU: the step got 8 %
-// slower.)
+// at a time: a correspondence is loaded once (from L2: a problem's rows are read by thousands
+// of waves) for two models; lanes stride over the rows; inlier count by ballot + popcount.
+//
+// The verdict of a (row, model) is that of inlier_of() -- projectPoints in fp64 in the
+// order of the sequential statement, squared error in fp32, err <= thr2 -- but it is
+// seldom COMPUTED that way.  A first pass evaluates the squared error in packed fp32 (both
+// models of the pair in one v_pk_* instruction) together with a bound B on how far that
+// value can lie from the one inlier_of() computes; err32 + B <= thr2 is a certain inlier,
+// err32 - B > thr2 a certain outlier, and only when some lane of the wave can say neither
+// (a point within about 0.5 % of the threshold circle, a point at almost no depth, a NaN
+// model) the wave runs inlier_of() for that batch of 64 rows.  Counts are therefore
+// identical to the exact evaluation, at about half its instructions.
+//
+// The bound (fast_verdicts): with u = 2^-24, S = |X| + |Y| + |Z| + max|t_i| >= the sum of
+// the magnitudes in a camera-frame coordinate (|R_ij| <= 1), every fp32 coordinate is within
+// 5 u S of the true one; with k = 2^-20 S / |z| (>= 3 x that over the depth) the quotient
+// x/z is off by at most k (1 + |q|) + 2^-21.4 |q|, the pixel by eps (G + |p - c| + |d|) with
+// eps = k + 2^-19 + 2^-21 + 2^-22, G = f + 2 |c|, and the same bounds hold, with room, for
+// the fp64 evaluation rounded to fp32 as inlier_of() does.  In squares (no absolute
+// values, which packed fp32 lacks): Delta^2 <= 4 (k^2 + ceps^2) (G^2 + 2 M^2),
+// M^2 = f^2 (qx^2 + qy^2) + err32, and |err32 - err| <= 2 sqrt(2 err32) Delta + 2 Delta^2 +
+// 8u err32 <= err32 / 512 + 1026 Delta^2 + 8u err32 for each of the two evaluations
+// (2ab <= a^2 / 512 + 512 b^2): B = err32 / 251 + 2075 Delta^2.  k <= 2^-4 is required (depth
+// not below S / 65536, so that the quotient's own error stays a small fraction of it), and
+// anything non-finite fails every comparison, i.e. is "uncertain".
+// tools/score_filter_check measures the bound against the exact error on benign and wild
+// models: no certain verdict differs, the observed |err32 - err| / B stays below 0.01.
+// (Staging the rows in LDS -- 40 KB per workgroup for 2000 rows -- was measured: alone the
+// kernel runs no faster, and the LDS it takes keeps solve workgroups of the next round off
+// the CU: the step got 8 % slower.)
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
+
+// Two models in fp32, component x = the first, y = the second.
+struct FastModels {
+    f2 R[9], t[3];
+    f2 tmax;          // max |t_i| of each model, rounded up
+    float fx, fy, cx, cy;
+    float f2max;      // max(fx, fy)^2, rounded up
+    float G2;         // (max(fx, fy) + 2 max(|cx|, |cy|))^2, rounded up
+};
+
+__device__ __forceinline__ FastModels fast_models(const double *Ra, const double *ta,
+                                                  const double *Rb, const double *tb, double fx,
+                                                  double fy, double cx, double cy)
+{
+    FastModels F;
+#pragma unroll
+    for (int e = 0; e < 9; e++)
+        F.R[e] = f2{(float)Ra[e], (float)Rb[e]};
+#pragma unroll
+    for (int e = 0; e < 3; e++)
+        F.t[e] = f2{(float)ta[e], (float)tb[e]};
+    const double ma = fmax(fabs(ta[0]), fmax(fabs(ta[1]), fabs(ta[2])));
+    const double mb = fmax(fabs(tb[0]), fmax(fabs(tb[1]), fabs(tb[2])));
+    F.tmax = f2{(float)(ma * 1.000001), (float)(mb * 1.000001)};
+    F.fx = (float)fx;
+    F.fy = (float)fy;
+    F.cx = (float)cx;
+    F.cy = (float)cy;
+    const double f = fmax(fabs(fx), fabs(fy)), c = fmax(fabs(cx), fabs(cy));
+    F.f2max = (float)(f * f * 1.000001);
+    F.G2 = (float)((f + 2 * c) * (f + 2 * c) * 1.000001);
+    return F;
+}
+
+// First pass of the scoring kernel for one row and two models: err32 and the bound B
+// (see the kernel's comment).  certain-inlier / certain-outlier / neither, per model.
+struct FastVerdict {
+    bool in_a, out_a, in_b, out_b; // "tame" already folded in: neither set = uncertain
+    f2 err, bound;
+};
+
+__device__ __forceinline__ FastVerdict fast_verdicts(const FastModels &F, float X, float Y, float Z,
+                                                     float u, float v, float thr2)
+{
+    const float C1 = 0x1p-20f, CE2 = 9.0e-12f /* > (2^-19 + 2^-21 + 2^-22)^2 */, K2MAX = 0x1p-8f;
+    const f2 x = fma2(F.R[2], splat2(Z), fma2(F.R[1], splat2(Y), fma2(F.R[0], splat2(X), F.t[0])));
+    const f2 y = fma2(F.R[5], splat2(Z), fma2(F.R[4], splat2(Y), fma2(F.R[3], splat2(X), F.t[1])));
+    const f2 z = fma2(F.R[8], splat2(Z), fma2(F.R[7], splat2(Y), fma2(F.R[6], splat2(X), F.t[2])));
+    const f2 iz = f2{__builtin_amdgcn_rcpf(z.x), __builtin_amdgcn_rcpf(z.y)};
+    const f2 qx = x * iz, qy = y * iz;
+    const f2 px = fma2(qx, splat2(F.fx), splat2(F.cx)), py = fma2(qy, splat2(F.fy), splat2(F.cy));
+    const f2 dx = splat2(u) - px, dy = splat2(v) - py;
+    const f2 e2 = fma2(dy, dy, dx * dx);
+    const float Sp = (fabsf(X) + fabsf(Y) + fabsf(Z)) * C1;
+    const f2 w = fma2(F.tmax, splat2(C1), splat2(Sp)) * iz; // k = 2^-20 S / z (its sign squares away)
+    const f2 k2 = w * w;
+    const f2 M2 = fma2(fma2(qy, qy, qx * qx), splat2(F.f2max), e2);
+    const f2 T = fma2(M2, splat2(2.f), splat2(F.G2));
+    const f2 D2 = (k2 + splat2(CE2)) * T;                       // Delta^2 / 4
+    const f2 B = fma2(D2, splat2(8300.f), e2 * splat2(0x1.05p-8f)); // err32 / 251 + 2075 Delta^2
+    const f2 up = e2 + B, dn = e2 - B;
+    FastVerdict r;
+    const bool tame_a = k2.x <= K2MAX, tame_b = k2.y <= K2MAX;
+    r.in_a = (up.x <= thr2) & tame_a;
+    r.out_a = (dn.x > thr2) & tame_a;
+    r.in_b = (up.y <= thr2) & tame_b;
+    r.out_b = (dn.y > thr2) & tame_b;
+    r.err = e2;
+    r.bound = B;
+    return r;
+}
+
+#ifdef SCORE_STATS
+// tools/score_filter_check: [0] (row, model) verdicts, [1] uncertain ones, [2] certain
+// verdicts that differ from inlier_of(), [3] batches of 64 rows sent to the exact path,
+// [4] batches, [5] max over certain verdicts of |err32 - err| / B as float bits.
+__device__ unsigned long long g_score_stats[8];
+__device__ __forceinline__ float exact_err(double X, double Y, double Z, float u, float v,
+                                           const double *R, const double *t, double fx, double fy,
+                                           double cx, double cy)
+{
+    double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    z = z ? 1. / z : 1;
+    x *= z;
+    y *= z;
+    const float px = (float)(x * fx + cx), py = (float)(y * fy + cy);
+    const float dx = u - px, dy = v - py;
+    return dx * dx + dy * dy;
+}
+#endif
+
 constexpr int SCORE_WAVES = 4;
 constexpr int SCORE_HPW = 2;
 constexpr int SCORE_HPB = SCORE_WAVES * SCORE_HPW;
@@ -1914,15 +2033,45 @@ __global__ __launch_bounds__(64 * SCORE_WAVES) void ransac_score_kernel(
         const int64_t row0 = begins ? begins[pa] : 0;
         const int rows = begins ? ends[pa] - begins[pa] : n;
         const float *o = obj + 3 * row0, *im = img + 2 * row0;
+        const FastModels F = fast_models(Ra, ta, Rb, tb, fx, fy, cx, cy);
         for (int base = 0; base < rows; base += 64) {
             const int i = base + lane;
             const bool in = i < rows;
             const int ii = in ? i : 0;
-            const double X = o[3 * ii], Y = o[3 * ii + 1], Z = o[3 * ii + 2];
+            const float Xf = o[3 * ii], Yf = o[3 * ii + 1], Zf = o[3 * ii + 2];
             const float u = im[2 * ii], v = im[2 * ii + 1];
-            // (no short circuit: both chains run on every lane and interleave)
-            const bool fa = inlier_of(X, Y, Z, u, v, Ra, ta, fx, fy, cx, cy, thr2) & in;
-            const bool fb = inlier_of(X, Y, Z, u, v, Rb, tb, fx, fy, cx, cy, thr2) & in;
+            const FastVerdict q = fast_verdicts(F, Xf, Yf, Zf, u, v, thr2);
+            const bool unsure = in & !((q.in_a | q.out_a) & (q.in_b | q.out_b));
+            bool fa = q.in_a & in, fb = q.in_b & in;
+#ifdef SCORE_STATS
+            {
+                const float ea = exact_err(Xf, Yf, Zf, u, v, Ra, ta, fx, fy, cx, cy);
+                const float eb = exact_err(Xf, Yf, Zf, u, v, Rb, tb, fx, fy, cx, cy);
+                const bool ca = in & (q.in_a | q.out_a), cb = in & (q.in_b | q.out_b);
+                const int wrong = (ca & (q.in_a != (ea <= thr2))) + (cb & (q.in_b != (eb <= thr2)));
+                const float ra = ca ? fabsf(q.err.x - ea) / q.bound.x : 0.f;
+                const float rb = cb ? fabsf(q.err.y - eb) / q.bound.y : 0.f;
+                const float rr = ra > rb ? ra : rb;
+                if (in) {
+                    atomicAdd(&g_score_stats[0], 2ull);
+                    atomicAdd(&g_score_stats[1], (unsigned long long)(!ca + !cb));
+                    atomicAdd(&g_score_stats[2], (unsigned long long)wrong);
+                    atomicMax(&g_score_stats[5], (unsigned long long)__float_as_uint(rr));
+                }
+                const bool slow = __ballot(unsure) != 0;
+                if (lane == 0) {
+                    atomicAdd(&g_score_stats[4], 1ull);
+                    if (slow)
+                        atomicAdd(&g_score_stats[3], 1ull);
+                }
+            }
+#endif
+            if (__ballot(unsure) != 0) { // rare: the exact evaluation for this batch of rows
+                double X = Xf, Y = Yf, Z = Zf;
+                KEEP(X); KEEP(Y); KEEP(Z); // (keeps the fp64 chains from being hoisted out of the branch)
+                fa = inlier_of(X, Y, Z, u, v, Ra, ta, fx, fy, cx, cy, thr2) & in;
+                fb = inlier_of(X, Y, Z, u, v, Rb, tb, fx, fy, cx, cy, thr2) & in;
+            }
             ga += __builtin_popcountll(__ballot(fa));
             gb += __builtin_popcountll(__ballot(fb));
         }
