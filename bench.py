@@ -113,6 +113,7 @@ def timed_region(step, steps, warmup, min_seconds, min_warmup_seconds, torch, di
             step()
         torch.cuda.synchronize()
         barrier()
+        torch.cuda.synchronize()
         el = time.perf_counter() - t0
         return all_reduce_max(el, torch, dist, dev, backend) if world > 1 else el
 
