@@ -1932,6 +1932,14 @@ __device__ __forceinline__ FastModels fast_models(const double *Ra, const double
     return F;
 }
 
+// Whether the fp32 first pass may be used for this pair of models at all (wave-uniform).
+__device__ __forceinline__ bool fast_models_usable(const FastModels &F)
+{
+    // false for NaN and infinity as well; the lower limit keeps 2^-20 S a normal number
+    return (F.tmax.x <= 0x1p59f) & (F.tmax.y <= 0x1p59f) & (F.tmax.x >= 0x1p-60f) &
+           (F.tmax.y >= 0x1p-60f);
+}
+
 // First pass of the scoring kernel for one row and two models: err32 and the bound B
 // (see the kernel's comment).  certain-inlier / certain-outlier / neither, per model.
 struct FastVerdict {
@@ -1951,7 +1959,8 @@ __device__ __forceinline__ FastVerdict fast_verdicts(const FastModels &F, float 
     const f2 px = fma2(qx, splat2(F.fx), splat2(F.cx)), py = fma2(qy, splat2(F.fy), splat2(F.cy));
     const f2 dx = splat2(u) - px, dy = splat2(v) - py;
     const f2 e2 = fma2(dy, dy, dx * dx);
-    const float Sp = (fabsf(X) + fabsf(Y) + fabsf(Z)) * C1;
+    const float S0 = fabsf(X) + fabsf(Y) + fabsf(Z);
+    const float Sp = S0 * C1;
     const f2 w = fma2(F.tmax, splat2(C1), splat2(Sp)) * iz; // k = 2^-20 S / z (its sign squares away)
     const f2 k2 = w * w;
     const f2 M2 = fma2(fma2(qy, qy, qx * qx), splat2(F.f2max), e2);
@@ -1960,7 +1969,12 @@ __device__ __forceinline__ FastVerdict fast_verdicts(const FastModels &F, float 
     const f2 B = fma2(D2, splat2(8300.f), e2 * splat2(0x1.05p-8f)); // err32 / 251 + 2075 Delta^2
     const f2 up = e2 + B, dn = e2 - B;
     FastVerdict r;
-    const bool tame_a = k2.x <= K2MAX, tame_b = k2.y <= K2MAX;
+    // (magnitudes: the caller admits only models with max |t_i| <= 2^59; with the row's
+    // coordinates below that too, no coordinate exceeds 2^60 and v_rcp_f32, which flushes
+    // denormal results to zero, stays in its accurate range; a depth too small for it
+    // comes back infinite and fails the k test)
+    const bool row_ok = S0 <= 0x1p59f;
+    const bool tame_a = (k2.x <= K2MAX) & row_ok, tame_b = (k2.y <= K2MAX) & row_ok;
     r.in_a = (up.x <= thr2) & tame_a;
     r.out_a = (dn.x > thr2) & tame_a;
     r.in_b = (up.y <= thr2) & tame_b;
@@ -2034,6 +2048,7 @@ __global__ __launch_bounds__(64 * SCORE_WAVES) void ransac_score_kernel(
         const int rows = begins ? ends[pa] - begins[pa] : n;
         const float *o = obj + 3 * row0, *im = img + 2 * row0;
         const FastModels F = fast_models(Ra, ta, Rb, tb, fx, fy, cx, cy);
+        const bool usable = __builtin_amdgcn_ballot_w64(!fast_models_usable(F)) == 0;
         for (int base = 0; base < rows; base += 64) {
             const int i = base + lane;
             const bool in = i < rows;
@@ -2041,13 +2056,13 @@ __global__ __launch_bounds__(64 * SCORE_WAVES) void ransac_score_kernel(
             const float Xf = o[3 * ii], Yf = o[3 * ii + 1], Zf = o[3 * ii + 2];
             const float u = im[2 * ii], v = im[2 * ii + 1];
             const FastVerdict q = fast_verdicts(F, Xf, Yf, Zf, u, v, thr2);
-            const bool unsure = in & !((q.in_a | q.out_a) & (q.in_b | q.out_b));
+            const bool unsure = in & !((q.in_a | q.out_a) & (q.in_b | q.out_b) & usable);
             bool fa = q.in_a & in, fb = q.in_b & in;
 #ifdef SCORE_STATS
             {
                 const float ea = exact_err(Xf, Yf, Zf, u, v, Ra, ta, fx, fy, cx, cy);
                 const float eb = exact_err(Xf, Yf, Zf, u, v, Rb, tb, fx, fy, cx, cy);
-                const bool ca = in & (q.in_a | q.out_a), cb = in & (q.in_b | q.out_b);
+                const bool ca = in & usable & (q.in_a | q.out_a), cb = in & usable & (q.in_b | q.out_b);
                 const int wrong = (ca & (q.in_a != (ea <= thr2))) + (cb & (q.in_b != (eb <= thr2)));
                 const float ra = ca ? fabsf(q.err.x - ea) / q.bound.x : 0.f;
                 const float rb = cb ? fabsf(q.err.y - eb) / q.bound.y : 0.f;

@@ -95,6 +95,23 @@ def test_full_size_config_hypotheses_exact(posehip):
     assert rel_translation_error(models[best, 3:], t) < 2e-2
 
 
+def test_degenerate_sample_with_huge_translation(posehip):
+    """A case found by tools/fuzz_counts.py: a degenerate 5-point sample whose EPnP solve puts
+    the camera 1e38 units away.  The depth's reciprocal is then a denormal in fp32, which the
+    scoring kernel's fp32 first pass must not rely on (it once read it as zero and counted a
+    row at the image centre as an inlier).  Inputs and the oracle's outputs are kept in
+    tests/golden/ransac_huge_translation.npz (8 samples around the failing one)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ransac_huge_translation.npz"))
+    models, counts = gpu_hypotheses(posehip, g["obj"], g["img"], datagen.CAMERA_K, g["sub"],
+                                    thr=float(g["thr"]))
+    assert np.abs(g["models"][3, 3:]).max() > 1e37          # the sample in question
+    rmodels, rcounts = orc.pnp_hypotheses(g["obj"], g["img"], datagen.CAMERA_K, g["sub"],
+                                          threshold=float(g["thr"]))
+    assert np.array_equal(rcounts, g["counts"]) and np.array_equal(counts, rcounts)
+    assert_models_equal(models, rmodels)
+
+
 def test_epnp_solve_matches_oracle(posehip):
     import poseestimation_amd as pa
     for n, seed in [(4, 1), (5, 2), (6, 3), (50, 4), (700, 5)]:

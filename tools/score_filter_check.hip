@@ -92,8 +92,9 @@ int main()
     }
     bad += score("camera inside the box");
     for (int h = 0; h < H; h++) { // huge and tiny magnitudes, NaN and infinity
-        const int kind = h % 4;
-        const double big = kind == 0 ? 1e6 : kind == 1 ? 1e-9 : kind == 2 ? 1e30 : 1.0;
+        const int kind = h % 8;
+        const double big = kind == 0 ? 1e6 : kind == 1 ? 1e-9 : kind == 2 ? 1e30 : kind == 3 ? 1.0
+                         : kind == 4 ? 3e38 : kind == 5 ? 1e-40 : kind == 6 ? 1e18 : 1e300;
         for (int k = 0; k < 3; k++) m[6 * h + k] = (kind == 2 ? 1e3 : 1.0) * U(rng);
         for (int k = 3; k < 6; k++) m[6 * h + k] = big * U(rng);
         if (h % 97 == 0) m[6 * h + 5] = NAN;
