@@ -337,6 +337,13 @@ ph_status ph_valu_popcount_peak(int iters, double *lane_ops_per_s);
 ph_status ph_valu_fp64_peak(int iters, double *fma_lane_ops_per_s,
                             double *mul_add_lane_ops_per_s);
 
+/* The EPnP solve of a batch of more than 64 hypotheses per CU exists twice, with
+ * bit-identical models: as one kernel (mode 0 / 1, the default: it measured fastest), and
+ * as two (mode 2: the 12 x 12 decomposition at two waves per SIMD, then the rest, handing
+ * over through a library workspace; mode 3: the second half at two waves per SIMD as well).
+ * A measurement and test aid, like ph_knn_set_path. */
+ph_status ph_ransac_set_solve_path(int mode);
+
 /* With profiling on (ph_set_profiling), ph_ransac_epnp_hypotheses[_batched]_dev records HIP
  * events on its stream around the solve kernel of its first round of hypotheses, around
  * the solve kernel of its last round (a call of at most one GPU-full -- 128 hypotheses per

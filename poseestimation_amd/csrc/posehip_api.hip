@@ -140,6 +140,7 @@ struct Context {
     DevBuf d_in;            // host entry points: device copy of the gathered inputs
     PinBuf h_in, h_out;     // host entry points: pinned gather buffer / zero-copy results
     DevBuf pnp_idx;         // RANSAC-EPnP: inlier rows of the refit
+    DevBuf pnp_front;       // RANSAC-EPnP: hand-over between the two solve kernels (one round)
     // Frame-offset tables of batched calls travel through a small ring of pinned
     // slots (one asynchronous copy each; a slot is reused once its call has finished).
     struct OffsetSlot {
@@ -606,6 +607,22 @@ ph_status check_pnp_args(const void *obj, const void *img, int n, const double *
 
 CameraK camera_of(const double *K) { return CameraK{K[0], K[4], K[2], K[5]}; }
 
+// The hand-over workspace of the two-kernel solve (ph_ransac_set_solve_path(2 | 3) only), for
+// calls large enough to take it (more than 64 hypotheses per CU).  It is shared by all
+// calls, like the matcher's.
+ph_status pnp_front_workspace(int64_t n_hyp, hipStream_t st, double *&front)
+{
+    front = nullptr;
+    if (ransac_solve_variant() < 2 || n_hyp <= (int64_t)g_ctx.n_cus * 64)
+        return PH_OK;
+    ph_status s = scratch_guard(st);
+    if (s != PH_OK)
+        return s;
+    PH_HIP(g_ctx.pnp_front.reserve(ransac_front_workspace_bytes(g_ctx.n_cus)));
+    front = (double *)g_ctx.pnp_front.p;
+    return PH_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -669,7 +686,7 @@ void ph_shutdown(void)
     }
     g_dbs.clear();
     DevBuf *all[] = {&g_ctx.part,  &g_ctx.part2, &g_ctx.best,   &g_ctx.tmp_i,
-                     &g_ctx.tmp_d, &g_ctx.d_in,  &g_ctx.pnp_idx, &g_ctx.xt};
+                     &g_ctx.tmp_d, &g_ctx.d_in,  &g_ctx.pnp_idx, &g_ctx.xt, &g_ctx.pnp_front};
     for (DevBuf *b : all)
         b->release();
     g_ctx.h_in.release();
@@ -816,6 +833,15 @@ ph_status ph_valu_fp64_peak(int iters, double *fma_lane_ops_per_s,
     PH_HIP(g_ctx.tmp_d.reserve((size_t)g_ctx.n_cus * 8 * 256 * sizeof(double)));
     PH_HIP(valu_fp64_peak(g_ctx.n_cus, iters, (double *)g_ctx.tmp_d.p, g_ctx.stream,
                           fma_lane_ops_per_s, mul_add_lane_ops_per_s));
+    return PH_OK;
+}
+
+ph_status ph_ransac_set_solve_path(int mode)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (mode < 0 || mode > 3)
+        return fail(PH_ERR_INVALID_ARG, "solve path must be 0 (default), 1, 2 or 3");
+    ransac_set_solve_variant(mode);
     return PH_OK;
 }
 
@@ -1430,9 +1456,12 @@ ph_status ph_ransac_epnp_hypotheses_dev(const float *d_obj, const float *d_img, 
         return fail(PH_ERR_INVALID_ARG, "need >= 5 correspondences and non-null buffers");
     const double thr = reproj_err;
     hipEvent_t *ev = g_ctx.profiling && n_hyp > 0 ? g_ctx.pnp_ev : nullptr;
+    double *front = nullptr;
+    if ((s = pnp_front_workspace(n_hyp, pick_stream(stream), front)) != PH_OK)
+        return s;
     PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, camera_of(K), d_subsets, nullptr, nullptr, 1,
                                     n_hyp, (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
-                                    pick_stream(stream), &g_ctx.pnp_overlap, ev));
+                                    pick_stream(stream), &g_ctx.pnp_overlap, ev, front));
     g_ctx.pnp_ev_valid = ev != nullptr;
     return PH_OK;
 }
@@ -1459,10 +1488,14 @@ ph_status ph_ransac_epnp_hypotheses_batched_dev(const float *d_obj, const float 
         return fail(PH_ERR_INVALID_ARG, "null pointer");
     const double thr = reproj_err;
     hipEvent_t *ev = g_ctx.profiling ? g_ctx.pnp_ev : nullptr;
+    double *front = nullptr;
+    if ((s = pnp_front_workspace((int64_t)n_problems * hyp_per_problem, pick_stream(stream),
+                                 front)) != PH_OK)
+        return s;
     PH_HIP(ransac_hypotheses_launch(d_obj, d_img, 0, camera_of(K), d_subsets, d_point_offsets,
                                     d_point_offsets + 1, n_problems, hyp_per_problem,
                                     (float)(thr * thr), d_models, d_counts, g_ctx.n_cus,
-                                    pick_stream(stream), &g_ctx.pnp_overlap, ev));
+                                    pick_stream(stream), &g_ctx.pnp_overlap, ev, front));
     g_ctx.pnp_ev_valid = ev != nullptr;
     return PH_OK;
 }

@@ -25,7 +25,16 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
                                     const int32_t *d_ends, int n_problems, int hyp_per_problem,
                                     float thr2, double *d_models, int32_t *d_counts, int n_cus,
                                     hipStream_t stream, const RansacOverlap *overlap = nullptr,
-                                    hipEvent_t *events = nullptr);
+                                    hipEvent_t *events = nullptr, double *d_front = nullptr);
+// d_front, when given (ransac_front_workspace_bytes(n_cus) bytes), lets a batch of more than
+// 64 hypotheses per CU take the two-kernel solve (decomposition at two waves per SIMD, then
+// the rest), one GPU-full of hypotheses per round.
+size_t ransac_front_workspace_bytes(int n_cus);
+// Which solve a large batch takes: 0 / 1 the single kernel (the default: it is the fastest),
+// 2 two kernels (second half at one wave per SIMD), 3 two kernels with the second half at
+// two waves per SIMD as well.  Bit-identical models either way.
+void ransac_set_solve_variant(int variant);
+int ransac_solve_variant();
 // events, when given (five of them), are recorded on `stream` around the first round's solve
 // kernel [0, 1], the last round's solve kernel [2, 3] (the same launch when the call is one
 // round) and the last round's scoring kernel [3, 4].

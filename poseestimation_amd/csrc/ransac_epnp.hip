@@ -1499,20 +1499,15 @@ enum PoseMode {
                   // candidates, whose pose step has such sums, run one after the other
 };
 
-// epnp::compute_pose on the correspondences P.  Returns true in the lane that reports
-// the result (one per problem).
-// HPW = problems per wave in the grouped modes (the lane stride between the members of
-// a group); the LDS element stride ST may be larger.
-// only = 1..3: run that candidate alone and report its R, t and reprojection error
-// *err_out; the caller applies the selection rule over the three.
+// First half of epnp::compute_pose: control points, barycentric basis, MtM and its 12 x 12
+// decomposition.  On return rows 8..11 of S.ut (the null-space vectors) and e.cws / e.ci
+// are everything the second half needs.
 template <int ST, PoseMode MODE = POSE_LANE, int HPW = ST>
-__device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3], double t[3],
-                          int lane = 0, int only = 0, double *err_out = nullptr)
+__device__ __forceinline__ void epnp_front(const Points &P, const EpnpLds<ST> &S, EpnpState &e,
+                                           int lane = 0)
 {
-    EpnpState e;
     constexpr int G = MODE == POSE_LANE ? 1 : 64 / HPW;
     const int member = MODE == POSE_LANE ? 0 : lane / HPW;
-    const LaneGroup grp = MODE == POSE_LANE ? LaneGroup() : LaneGroup{member, lane % HPW, HPW, G};
     PNP_STAMP(0);
     choose_control_points(P, e, S);
     PNP_STAMP(1);
@@ -1532,6 +1527,22 @@ __device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S,
         jacobi_svd_12<ST>(S.ut, S.w);
     }
     PNP_STAMP(4);
+}
+
+// Second half of epnp::compute_pose, from the null-space vectors in rows 8..11 of S.ut and
+// e.cws / e.ci.  Returns true in the lane that reports the result (one per problem).
+// HPW = problems per wave in the grouped modes (the lane stride between the members of
+// a group); the LDS element stride ST may be larger.
+// only = 1..3: run that candidate alone and report its R, t and reprojection error
+// *err_out; the caller applies the selection rule over the three.
+template <int ST, PoseMode MODE = POSE_LANE, int HPW = ST>
+__device__ __forceinline__ bool epnp_back(const Points &P, const EpnpLds<ST> &S, EpnpState &e,
+                                          double R[3][3], double t[3], int lane = 0, int only = 0,
+                                          double *err_out = nullptr)
+{
+    constexpr int G = MODE == POSE_LANE ? 1 : 64 / HPW;
+    const int member = MODE == POSE_LANE ? 0 : lane / HPW;
+    const LaneGroup grp = MODE == POSE_LANE ? LaneGroup() : LaneGroup{member, lane % HPW, HPW, G};
     NullRows<ST> N;
     detach_null_rows(S, N);
     compute_L_6x10(N, S.l);
@@ -1640,6 +1651,16 @@ __device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S,
     if (err_out)
         *err_out = best_err;
     return MODE == POSE_HELPED ? member == 0 : true;
+}
+
+// epnp::compute_pose on the correspondences P: both halves in one go.
+template <int ST, PoseMode MODE = POSE_LANE, int HPW = ST>
+__device__ __forceinline__ bool epnp_pose(const Points &P, const EpnpLds<ST> &S, double R[3][3], double t[3],
+                          int lane = 0, int only = 0, double *err_out = nullptr)
+{
+    EpnpState e;
+    epnp_front<ST, MODE, HPW>(P, S, e, lane);
+    return epnp_back<ST, MODE, HPW>(P, S, e, R, t, lane, only, err_out);
 }
 
 // cv::Rodrigues matrix -> vector (R re-orthonormalised by SVD first).
@@ -1789,6 +1810,91 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(const float *__restric
         return;
     rodrigues_mat_to_vec(S, R, r);
     PNP_STAMP(15);
+    double *m = models + (int64_t)h * 6;
+    m[0] = r[0]; m[1] = r[1]; m[2] = r[2];
+    m[3] = t[0]; m[4] = t[1]; m[5] = t[2];
+}
+
+// The solve of a large batch as TWO kernels -- an experiment that is kept selectable
+// (ransac_set_solve_variant) but is NOT the default, because it measured slower.  The
+// 12 x 12 decomposition (60 % of a solve) needs few registers beside its two rows, so the
+// first half can run with TWO waves per SIMD: 16 hypotheses per wave, four lanes per
+// hypothesis, LDS stride 16 -- 8 workgroups of 20 KB per CU, the same 128 hypotheses per CU
+// as the single kernel.  It hands the null-space vectors (rows 8..11 of ut), the control
+// points and the basis inverse to the second half through HBM, 69 doubles per hypothesis,
+// element-major (front[e * stride + slot], so that a wave's accesses coalesce).  Every
+// operation of a hypothesis is the one ransac_solve_kernel performs, in its order: the
+// models are bit-identical.  Measured per 32 768 hypotheses: first half 266-283 us + second
+// half 144-154 us against 392-408 us for the single kernel.  The reason is the fp64 pipe: a
+// lone wave issues an fp64 instruction every 7.2 clocks, two waves on a SIMD one every 5.7
+// between them (the pipe's limit is 4.5), so the second wave adds a quarter, not a half,
+// which the 23 rounds per sweep of four lanes per matrix against 35 of two lanes at twice
+// the hypotheses per wave give back exactly.
+constexpr int FRONT_DOUBLES = 48 + 12 + 9;
+
+template <int HPW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_front_kernel(
+    const float *__restrict__ obj, const float *__restrict__ img, CameraK K,
+    const int32_t *__restrict__ subsets, const int32_t *__restrict__ begins, int hyp_per_problem,
+    int h0, int n_hyp, double *__restrict__ front, int64_t stride)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, hl = lane % HPW;
+    const int h = h0 + blockIdx.x * HPW + hl;
+    if (h >= n_hyp)
+        return;
+    const EpnpLds<HPW> S((lds_double *)lds + hl);
+    const int64_t row0 = begins ? begins[h / hyp_per_problem] : 0;
+    const Points P = make_points(obj + 3 * row0, img + 2 * row0, subsets + (int64_t)h * 5, 5, K);
+    EpnpState e;
+    epnp_front<HPW, POSE_HELPED, HPW>(P, S, e, lane);
+    if (lane >= HPW) // every member of a group holds the same values: the first one reports
+        return;
+    double *out = front + (h - h0);
+#pragma unroll
+    for (int k = 0; k < 48; k++)
+        out[k * stride] = S.ut[96 + k];
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+        out[(48 + k) * stride] = e.cws[k / 3][k % 3];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        out[(60 + k) * stride] = e.ci[k];
+}
+
+template <int HPW, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
+void ransac_back_kernel(const float *__restrict__ obj, const float *__restrict__ img, CameraK K,
+                        const int32_t *__restrict__ subsets, const int32_t *__restrict__ begins,
+                        int hyp_per_problem, int h0, int n_hyp, const double *__restrict__ front,
+                        int64_t stride, double *__restrict__ models)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, hl = lane % HPW;
+    const int h = h0 + blockIdx.x * HPW + hl;
+    if (h >= n_hyp)
+        return;
+    constexpr int ST = WAVES_PER_SIMD > 1 ? HPW : (HPW < LDS_MIN_STRIDE ? LDS_MIN_STRIDE : HPW);
+    const EpnpLds<ST> S((lds_double *)lds + hl);
+    const int64_t row0 = begins ? begins[h / hyp_per_problem] : 0;
+    const Points P = make_points(obj + 3 * row0, img + 2 * row0, subsets + (int64_t)h * 5, 5, K);
+    EpnpState e;
+    const double *in = front + (h - h0);
+    // (the members of a group all write the same values to the same words)
+#pragma unroll
+    for (int k = 0; k < 48; k++)
+        S.ut[96 + k] = in[k * stride];
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+        e.cws[k / 3][k % 3] = in[(48 + k) * stride];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        e.ci[k] = in[(60 + k) * stride];
+    wave_sync();
+    double R[3][3], t[3], r[3];
+    if (!epnp_back<ST, POSE_HELPED, HPW>(P, S, e, R, t, lane))
+        return;
+    rodrigues_mat_to_vec(S, R, r);
     double *m = models + (int64_t)h * 6;
     m[0] = r[0]; m[1] = r[1]; m[2] = r[2];
     m[3] = t[0]; m[4] = t[1]; m[5] = t[2];
@@ -2291,12 +2397,55 @@ static hipError_t launch_solve3(const float *d_obj, const float *d_img, CameraK 
     return hipGetLastError();
 }
 
+// The two-kernel solve (ransac_front_kernel + ransac_back_kernel) of hypotheses [h0, n_hyp);
+// d_front: FRONT_DOUBLES * (n_hyp - h0) doubles of workspace.
+template <int BACK_HPW, int BACK_WAVES>
+static hipError_t launch_solve_split(const float *d_obj, const float *d_img, CameraK K,
+                                     const int32_t *d_subsets, const int32_t *d_begins,
+                                     int hyp_per_problem, int h0, int n_hyp, double *d_models,
+                                     double *d_front, hipStream_t stream)
+{
+    constexpr int FRONT_HPW = 16;
+    const int count = n_hyp - h0;
+    const size_t lds_front = (size_t)FRONT_HPW * LDS_DOUBLES * sizeof(double);
+    constexpr int BACK_ST =
+        BACK_WAVES > 1 ? BACK_HPW : (BACK_HPW < LDS_MIN_STRIDE ? LDS_MIN_STRIDE : BACK_HPW);
+    const size_t lds_back = (size_t)BACK_ST * LDS_DOUBLES * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void *)ransac_front_kernel<FRONT_HPW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_front);
+    if (e != hipSuccess)
+        return e;
+    e = hipFuncSetAttribute((const void *)ransac_back_kernel<BACK_HPW, BACK_WAVES>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back);
+    if (e != hipSuccess)
+        return e;
+    ransac_front_kernel<FRONT_HPW><<<(count + FRONT_HPW - 1) / FRONT_HPW, 64, lds_front, stream>>>(
+        d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, n_hyp, d_front, count);
+    if ((e = hipGetLastError()) != hipSuccess)
+        return e;
+    ransac_back_kernel<BACK_HPW, BACK_WAVES>
+        <<<(count + BACK_HPW - 1) / BACK_HPW, 64, lds_back, stream>>>(
+            d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, n_hyp, d_front, count,
+            d_models);
+    return hipGetLastError();
+}
+
+static int g_solve_variant = 0;
+
+void ransac_set_solve_variant(int variant) { g_solve_variant = variant; }
+int ransac_solve_variant() { return g_solve_variant; }
+
+size_t ransac_front_workspace_bytes(int n_cus)
+{
+    return (size_t)FRONT_DOUBLES * (size_t)n_cus * 128 * sizeof(double);
+}
+
 hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int n, CameraK K,
                                     const int32_t *d_subsets, const int32_t *d_begins,
                                     const int32_t *d_ends, int n_problems, int hyp_per_problem,
                                     float thr2, double *d_models, int32_t *d_counts, int n_cus,
                                     hipStream_t stream, const RansacOverlap *overlap,
-                                    hipEvent_t *events)
+                                    hipEvent_t *events, double *d_front)
 {
     const int64_t total = (int64_t)n_problems * hyp_per_problem;
     if (total <= 0)
@@ -2323,9 +2472,14 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     // kernel leaves most of every SIMD's issue slots and registers for one more wave).
     const int round = n_cus * 128;
     const bool split = overlap && !small && n_hyp > round;
+    // Large batches take the two-kernel solve when the caller brought its workspace (which
+    // holds one round: such a batch then always goes down in rounds).
+    const int variant = g_solve_variant;
+    const bool two_kernel = !small && d_front != nullptr && variant >= 2;
+    const bool rounds = split || (two_kernel && n_hyp > round);
     hipError_t e;
-    for (int h0 = 0; h0 < n_hyp; h0 += split ? round : n_hyp) {
-        const int h1 = split ? (n_hyp - h0 > round ? h0 + round : n_hyp) : n_hyp;
+    for (int h0 = 0; h0 < n_hyp; h0 += rounds ? round : n_hyp) {
+        const int h1 = rounds ? (n_hyp - h0 > round ? h0 + round : n_hyp) : n_hyp;
         const bool first = h0 == 0;
         if (events && first && (e = hipEventRecord(events[0], stream)) != hipSuccess)
             return e;
@@ -2343,6 +2497,12 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
         else if (small)
             e = launch_solve<16>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
                                  d_models, stream);
+        else if (two_kernel && variant == 3)
+            e = launch_solve_split<16, 2>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0,
+                                          h1, d_models, d_front, stream);
+        else if (two_kernel)
+            e = launch_solve_split<32, 1>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0,
+                                          h1, d_models, d_front, stream);
         else
             e = launch_solve<32>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
                                  d_models, stream);

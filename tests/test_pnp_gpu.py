@@ -384,3 +384,15 @@ def test_every_solve_kernel_gives_the_same_models(posehip):
     rm, rc = orc.pnp_hypotheses(obj, img, datagen.CAMERA_K, sub[:256], threads=8)
     assert np.array_equal(c_ref[:256], rc)
     assert np.array_equal(np.isnan(m_ref[:256]), np.isnan(rm))
+    # the two-kernel forms of the large-batch solve (kept selectable; the single kernel is
+    # the default) give the same bits, also across a round boundary (40 000 > 32 768)
+    sub2 = orc.ransac_subsets(400, 40000)
+    m1, c1 = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, sub2)
+    try:
+        for mode in (2, 3):
+            posehip.check(posehip.load().ph_ransac_set_solve_path(mode))
+            m2, c2 = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, sub2)
+            assert np.array_equal(c2, c1), mode
+            assert np.array_equal(m2.view(np.uint64), m1.view(np.uint64)), mode
+    finally:
+        posehip.load().ph_ransac_set_solve_path(0)
