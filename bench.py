@@ -165,13 +165,20 @@ def ransac_roofline(args, torch, lib, _lib, step, problems, hyps, n_points):
     achieved = hyps_per_launch * solve_flop / (solve_ms * 1e-3)
     peak = 2.0 * fma.value
     score_ms = float(np.mean(score))
+    traffic = None   # HBM bytes per solve launch from the PMC passes of the same shape
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_ransac_16x4096x2000.json")))
+        if (problems, hyps, n_points) == (16, 4096, 2000):
+            traffic = pmc["derived"]["void posehip::ransac_solve_kernel<32>"]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     return {
         "bound": "fp64 valu",
         "kernel": "ransac_solve_kernel<32>",
         "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
         "frac": achieved / peak,
         "frac_of_mul_add_rate": achieved / mix.value,
-        "traffic": None,
+        "traffic": traffic,
         "kernel_ms": solve_ms,
         "first_round_kernel_ms": float(np.mean(first)),
         "last_round_kernel_ms": float(np.mean(last)),

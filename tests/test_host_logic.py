@@ -2,6 +2,7 @@
 filter and the reference's min-distance filter, against the oracle; and the refusal of
 every compute entry point before ph_init (no CPU fallback)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -72,3 +73,17 @@ def test_compute_entry_points_refuse_without_init():
                                        100, 8.0, 0.99, 1, r.ctypes.data_as(dp), r.ctypes.data_as(dp), None,
                                        None, C.byref(found), None) == 4
     assert b"ph_init" in lib.ph_last_error_string()
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` started bare launches its own ranks -- and exits non-zero, before
+    any GPU call, when the node has fewer than N GPUs (here: none)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert out.returncode == 2 and "--gpus 2" in out.stderr
