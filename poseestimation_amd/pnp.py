@@ -102,18 +102,22 @@ def solvePnPRansacBatch(objectPointsList, imagePointsList, cameraMatrix, distCoe
     P = len(objectPointsList)
     if P == 0:
         return []
-    objs = [np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3) for o in objectPointsList]
-    imgs = [np.ascontiguousarray(i, dtype=np.float32).reshape(-1, 2) for i in imagePointsList]
-    for o, i in zip(objs, imgs):
-        if o.shape[0] != i.shape[0]:
-            raise ValueError("objectPoints and imagePoints of a frame differ in length")
+    # pack every frame's points into one buffer each (np.concatenate converts to float32 while
+    # it copies; frames given as (n, 1, 3) / (n, 1, 2), as cv2 accepts them, are flattened first)
+    objs = [o if getattr(o, "ndim", 0) == 2 else np.asarray(o).reshape(-1, 3) for o in objectPointsList]
+    imgs = [i if getattr(i, "ndim", 0) == 2 else np.asarray(i).reshape(-1, 2) for i in imagePointsList]
+    counts = [o.shape[0] for o in objs]
+    if counts != [i.shape[0] for i in imgs]:
+        raise ValueError("objectPoints and imagePoints of a frame differ in length")
+    if any(o.shape[1] != 3 for o in objs) or any(i.shape[1] != 2 for i in imgs):
+        raise ValueError("objectPoints must be (n, 3) and imagePoints (n, 2)")
     off = np.zeros(P + 1, np.int32)
-    off[1:] = np.cumsum([o.shape[0] for o in objs])
+    np.cumsum(counts, out=off[1:])
     total = int(off[-1])
-    obj = np.concatenate(objs) if total else np.zeros((1, 3), np.float32)
-    img = np.concatenate(imgs) if total else np.zeros((1, 2), np.float32)
-    rvecs, tvecs = np.zeros((P, 3)), np.zeros((P, 3))
-    inl = np.zeros(max(total, 1), np.int32)
+    obj = np.concatenate(objs, dtype=np.float32, casting="unsafe") if total else np.zeros((1, 3), np.float32)
+    img = np.concatenate(imgs, dtype=np.float32, casting="unsafe") if total else np.zeros((1, 2), np.float32)
+    rvecs, tvecs = np.zeros((P, 3, 1)), np.zeros((P, 3, 1))
+    inl = np.zeros((max(total, 1), 1), np.int32)
     n_inl, found, iters = (np.zeros(P, np.int32) for _ in range(3))
     i32 = C.POINTER(C.c_int32)
     _lib.check(_lib.load().ph_solvepnp_ransac_epnp_batched(
@@ -121,12 +125,9 @@ def solvePnPRansacBatch(objectPointsList, imagePointsList, cameraMatrix, distCoe
         float(reprojectionError), float(confidence), int(rngState), _dp(rvecs), _dp(tvecs),
         inl.ctypes.data_as(i32), n_inl.ctypes.data_as(i32), found.ctypes.data_as(i32),
         iters.ctypes.data_as(i32)))
-    out = []
-    for p in range(P):
-        r, t = rvecs[p].reshape(3, 1).copy(), tvecs[p].reshape(3, 1).copy()
-        if found[p]:
-            res = (True, r, t, inl[off[p]:off[p] + n_inl[p]].reshape(-1, 1).copy())
-        else:
-            res = (False, r, t, None)
-        out.append(res + (int(iters[p]),) if returnIterations else res)
-    return out
+    # the results are views of this call's own arrays (nothing of the library's is aliased)
+    lo, hi = off[:-1].tolist(), (off[:-1] + n_inl).tolist()
+    ok, its = found.astype(bool).tolist(), iters.tolist()
+    if returnIterations:
+        return [(ok[p], rvecs[p], tvecs[p], inl[lo[p]:hi[p]] if ok[p] else None, its[p]) for p in range(P)]
+    return [(ok[p], rvecs[p], tvecs[p], inl[lo[p]:hi[p]] if ok[p] else None) for p in range(P)]
