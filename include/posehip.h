@@ -235,8 +235,11 @@ ph_status ph_match_crosscheck_hamming256_shard_dev(const void *d_query, int64_t 
  * obj: n x 3 float model points, img: n x 2 float pixels, K: row-major 3 x 3.
  * rng_state seeds OpenCV's multiply-with-carry cv::RNG; OpenCV itself always
  * uses 0xFFFFFFFFFFFFFFFF.  *found = 1 iff a pose was found (OpenCV's return
- * value); rvec/tvec then hold the EPnP refit over all inliers, inliers (n
- * entries, may be NULL) their ascending row indices.  iterations_run (may be
+ * value); rvec/tvec then hold the EPnP refit over all inliers (OpenCV hands
+ * that solve the consensus set as CV_64F points, so the normalised image
+ * points are not rounded to float on the way in, unlike in the per-sample
+ * solves; reproduced), inliers (n entries, may be NULL) their ascending row
+ * indices.  iterations_run (may be
  * NULL) = RANSAC iterations consumed after the adaptive budget cut.  n < 5 is
  * PH_ERR_INVALID_ARG (OpenCV asserts n >= 4 and uses P3P at n == 4, which is
  * outside this path). */
@@ -267,8 +270,9 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
                                           int32_t *found, int32_t *iterations_run);
 
 /* cv::solvePnP(obj, img, K, noArray(), rvec, tvec, false, SOLVEPNP_EPNP) on
- * n >= 4 correspondences (the per-sample kernel and the final refit of the call
- * above). */
+ * n >= 4 correspondences given as CV_32F points (what RANSAC's per-sample solve
+ * is; the final refit of the call above differs only in taking its points as
+ * CV_64F). */
 ph_status ph_solvepnp_epnp(const float *obj, const float *img, int n, const double *K,
                            double *rvec, double *tvec);
 

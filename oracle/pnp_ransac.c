@@ -688,11 +688,16 @@ static double compute_R_and_t(epnp_t *e, const double *ut, const double *betas, 
 /*
  * solvePnP(SOLVEPNP_EPNP) up to (R, t): image points are first normalised by
  * undistortPoints (zero distortion: x = (u - cx)/fx computed in double, stored
- * in the input's float type), then epnp::init_points maps them back with
- * us = x*fu + uc.  obj: n x 3 float, img: n x 2 float, K row-major 3 x 3.
+ * in the type of the points it was given), then epnp::init_points maps them
+ * back with us = x*fu + uc.  points_are_f32 != 0: the points reach solvePnP as
+ * CV_32F (the caller's arrays, RANSAC's five-point samples), so x is rounded to
+ * float on the way; 0: they reach it as CV_64F (solvePnPRansac converts the
+ * consensus set to Point3d / Point2d before its final solve), so x stays double.
+ * obj: n x 3 float, img: n x 2 float (the values are floats either way), K
+ * row-major 3 x 3.
  */
-static int epnp_pose(const float *obj, const float *img, int n, const double *K, double R[3][3],
-                     double t[3])
+static int epnp_pose(const float *obj, const float *img, int n, const double *K, int points_are_f32,
+                     double R[3][3], double t[3])
 {
     epnp_t e;
     e.fu = K[0]; e.fv = K[4]; e.uc = K[2]; e.vc = K[5];
@@ -710,8 +715,12 @@ static int epnp_pose(const float *obj, const float *img, int n, const double *K,
         e.pws[3 * i] = obj[3 * i];
         e.pws[3 * i + 1] = obj[3 * i + 1];
         e.pws[3 * i + 2] = obj[3 * i + 2];
-        float xn = (float)(((double)img[2 * i] - K[2]) * ifx);
-        float yn = (float)(((double)img[2 * i + 1] - K[5]) * ify);
+        double xn = ((double)img[2 * i] - K[2]) * ifx;
+        double yn = ((double)img[2 * i + 1] - K[5]) * ify;
+        if (points_are_f32) {
+            xn = (float)xn;
+            yn = (float)yn;
+        }
         e.us[2 * i] = xn * e.fu + e.uc;
         e.us[2 * i + 1] = yn * e.fv + e.vc;
     }
@@ -840,20 +849,34 @@ void orc_rodrigues_mat_to_vec(const double *R9, double *r3)
 
 void orc_rodrigues_vec_to_mat(const double *r3, double *R9) { rodrigues_vec_to_mat(r3, R9); }
 
-/* solvePnP(obj, img, K, no distortion, SOLVEPNP_EPNP) -> rvec, tvec. */
-int orc_solvepnp_epnp(const float *obj, const float *img, int n, const double *K, double *rvec,
-                      double *tvec)
+static int solvepnp_epnp(const float *obj, const float *img, int n, const double *K,
+                         int points_are_f32, double *rvec, double *tvec)
 {
     double R[3][3], t[3];
     if (n < 4)
         return -1;
-    if (epnp_pose(obj, img, n, K, R, t) != 0)
+    if (epnp_pose(obj, img, n, K, points_are_f32, R, t) != 0)
         return -1;
     rodrigues_mat_to_vec(R, rvec);
     tvec[0] = t[0];
     tvec[1] = t[1];
     tvec[2] = t[2];
     return 0;
+}
+
+/* solvePnP(obj, img, K, no distortion, SOLVEPNP_EPNP) on CV_32F points -> rvec, tvec. */
+int orc_solvepnp_epnp(const float *obj, const float *img, int n, const double *K, double *rvec,
+                      double *tvec)
+{
+    return solvepnp_epnp(obj, img, n, K, 1, rvec, tvec);
+}
+
+/* The same on the values of float points handed over as CV_64F, which is how solvePnPRansac
+ * calls solvePnP on its consensus set. */
+int orc_solvepnp_epnp_f64points(const float *obj, const float *img, int n, const double *K,
+                                double *rvec, double *tvec)
+{
+    return solvepnp_epnp(obj, img, n, K, 0, rvec, tvec);
 }
 
 /*
@@ -1030,7 +1053,8 @@ int orc_solvepnp_ransac(const float *obj, const float *img, int n, const double 
         *iters_run = iter;
     int result = 0;
     if (max_good > 0) {
-        /* refit on the inliers (points converted to double and back: exact for float inputs) */
+        /* refit on the inliers, converted to CV_64F (exact for float inputs; what changes is
+         * that undistortPoints then keeps the normalised image points in double) */
         float *io = (float *)malloc(sizeof(float) * 5 * (size_t)max_good);
         if (io) {
             float *ii = io + 3 * (size_t)max_good;
@@ -1042,7 +1066,7 @@ int orc_solvepnp_ransac(const float *obj, const float *img, int n, const double 
                     inliers[k] = i;
                     k++;
                 }
-            if (orc_solvepnp_epnp(io, ii, k, K, rvec, tvec) == 0) {
+            if (orc_solvepnp_epnp_f64points(io, ii, k, K, rvec, tvec) == 0) {
                 result = 1;
                 if (n_inliers)
                     *n_inliers = k;

@@ -1026,6 +1026,9 @@ struct Points {
     // and combine their partial sums with wave_sum().
     int first, step;
     double fu, fv, uc, vc, ifx, ify;
+    // The points reach solvePnP as CV_32F (the caller's arrays, RANSAC's samples) or as CV_64F
+    // (solvePnPRansac converts the consensus set to Point3d / Point2d before its final solve).
+    bool points_are_f32;
     __device__ void world(int i, double *pw) const
     {
         const int64_t r = idx ? idx[i] : i;
@@ -1033,12 +1036,17 @@ struct Points {
         pw[1] = obj[3 * r + 1];
         pw[2] = obj[3 * r + 2];
     }
-    // undistortPoints with zero distortion stores (u - cx)/fx as float; EPnP maps it back.
+    // undistortPoints with zero distortion stores (u - cx)/fx in the type of the points it was
+    // given (rounded to float for CV_32F points, kept for CV_64F ones); EPnP maps it back.
     __device__ void pixel(int i, double &u, double &v) const
     {
         const int64_t r = idx ? idx[i] : i;
-        const float xn = (float)(((double)img[2 * r] - uc) * ifx);
-        const float yn = (float)(((double)img[2 * r + 1] - vc) * ify);
+        double xn = ((double)img[2 * r] - uc) * ifx;
+        double yn = ((double)img[2 * r + 1] - vc) * ify;
+        if (points_are_f32) {
+            xn = (float)xn;
+            yn = (float)yn;
+        }
         u = xn * fu + uc;
         v = yn * fv + vc;
     }
@@ -1761,9 +1769,10 @@ __device__ inline bool is_inlier(const float *obj, const float *img, int64_t i, 
 }
 
 __device__ inline Points make_points(const float *obj, const float *img, const int32_t *idx, int n,
-                                     CameraK K)
+                                     CameraK K, bool points_are_f32 = true)
 {
     Points P;
+    P.points_are_f32 = points_are_f32;
     P.obj = obj;
     P.img = img;
     P.idx = idx;
@@ -2321,8 +2330,10 @@ __global__ __launch_bounds__(64 * REFIT_WAVES) void epnp_refit_batched_kernel(
     img += 2 * row0;
     int32_t *list = idx_dev + row0;
     int k = 0;
+    // a problem of exactly five rows is solved on the caller's float points; a consensus set is
+    // converted to CV_64F first
+    const bool all = begins ? use_all_rows[b] != 0 : false;
     {
-        const bool all = begins ? use_all_rows[b] != 0 : false;
         // constant indices: a loop over one.best would put the by-value struct in scratch
         double rv[3] = {one.best[0], one.best[1], one.best[2]};
         double tv[3] = {one.best[3], one.best[4], one.best[5]};
@@ -2353,7 +2364,7 @@ __global__ __launch_bounds__(64 * REFIT_WAVES) void epnp_refit_batched_kernel(
         for (int i = lane; i < k; i += 64)
             idx_out[row0 + i] = list[i];
     double r[3], t[3];
-    if (epnp_solve_three_waves(make_points(obj, img, list, k, K), (lds_double *)lds, r, t) &&
+    if (epnp_solve_three_waves(make_points(obj, img, list, k, K, all), (lds_double *)lds, r, t) &&
         threadIdx.x == 0) {
         double *model = models_out + (int64_t)b * 6;
         model[0] = r[0]; model[1] = r[1]; model[2] = r[2];

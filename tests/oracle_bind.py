@@ -64,6 +64,8 @@ def load():
     lib.orc_rodrigues_vec_to_mat.argtypes = [_f64p, _f64p]
     lib.orc_solvepnp_epnp.restype = C.c_int
     lib.orc_solvepnp_epnp.argtypes = [_f32p, _f32p, C.c_int, _f64p, _f64p, _f64p]
+    lib.orc_solvepnp_epnp_f64points.restype = C.c_int
+    lib.orc_solvepnp_epnp_f64points.argtypes = [_f32p, _f32p, C.c_int, _f64p, _f64p, _f64p]
     lib.orc_pnp_count_inliers.restype = C.c_int
     lib.orc_pnp_count_inliers.argtypes = [_f32p, _f32p, C.c_int, _f64p, _f64p, _f64p, C.c_double,
                                           _u8p, _f32p]
@@ -188,10 +190,13 @@ def rodrigues(x):
     return R.reshape(3, 3)
 
 
-def solvepnp_epnp(obj, img, K):
+def solvepnp_epnp(obj, img, K, points_as_f64=False):
+    """solvePnP(SOLVEPNP_EPNP) on float points; points_as_f64: the same values handed over as
+    CV_64F, as solvePnPRansac does with its consensus set."""
     obj, img, K = _f32(obj, 3), _f32(img, 2), _K(K)
     r, t = np.empty(3), np.empty(3)
-    rc = load().orc_solvepnp_epnp(_fp(obj), _fp(img), obj.shape[0], _dp(K), _dp(r), _dp(t))
+    fn = load().orc_solvepnp_epnp_f64points if points_as_f64 else load().orc_solvepnp_epnp
+    rc = fn(_fp(obj), _fp(img), obj.shape[0], _dp(K), _dp(r), _dp(t))
     assert rc == 0
     return r, t
 

@@ -117,3 +117,19 @@ def test_multithreaded_hypotheses_equal_single():
     a = orc.pnp_hypotheses(obj, img, datagen.CAMERA_K, subsets)
     b = orc.pnp_hypotheses(obj, img, datagen.CAMERA_K, subsets, threads=4)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_ransac_final_solve_takes_the_consensus_set_as_f64_points():
+    """solvePnPRansac converts its consensus set to Point3d / Point2d before the final
+    solvePnP, so undistortPoints keeps the normalised image points in double there, while
+    the caller's CV_32F points (and RANSAC's samples) are rounded to float on the way.
+    The final pose equals the f64-points solve on the inliers bit for bit, and differs from
+    the f32-points solve of the same rows by float rounding only."""
+    obj, img, R, t, _ = datagen.pnp_scene(n=400, outlier_frac=0.3, seed=12)
+    ok, rvec, tvec, inl, _ = orc.solvepnp_ransac(obj, img, datagen.CAMERA_K, iterations=100)
+    assert ok and len(inl) >= 200
+    r64, t64 = orc.solvepnp_epnp(obj[inl], img[inl], datagen.CAMERA_K, points_as_f64=True)
+    assert np.array_equal(rvec, r64) and np.array_equal(tvec, t64)
+    r32, t32 = orc.solvepnp_epnp(obj[inl], img[inl], datagen.CAMERA_K)
+    assert not (np.array_equal(r32, r64) and np.array_equal(t32, t64))
+    assert np.abs(r32 - r64).max() < 1e-6 and np.abs(t32 - t64).max() < 1e-5
