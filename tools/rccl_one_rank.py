@@ -33,6 +33,9 @@ d_t[:5000] = d_q[:5000]          # exact copies: the cross-check has matches to 
 stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
     dist.barrier()
+    el = torch.tensor([1.25], dtype=torch.float64, device=dev)   # the benchmark's MAX over ranks
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    assert float(el.item()) == 1.25
     idx, dst, keep = knn_train_sharded(d_q, d_t, 0, 2, ratio=0.75)
     cidx, cdst = match_crosscheck_train_sharded(d_q, d_t, 0)
     stream.synchronize()
