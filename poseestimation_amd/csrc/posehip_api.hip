@@ -1705,14 +1705,10 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
         return fail(PH_ERR_INVALID_ARG, "point_offsets, rvecs, tvecs and found must be non-null");
     if (point_offsets[0] < 0)
         return fail(PH_ERR_INVALID_ARG, "negative offset");
-    int max_n = 0;
-    for (int p = 0; p < n_problems; p++) {
-        const int64_t c = (int64_t)point_offsets[p + 1] - point_offsets[p];
-        if (c < 0)
+    for (int p = 0; p < n_problems; p++)
+        if (point_offsets[p + 1] < point_offsets[p])
             return fail(PH_ERR_INVALID_ARG, "offsets of problem %d are not ascending", p);
-        max_n = std::max(max_n, (int)c);
-    }
-    const int row_lo = point_offsets[0], row_hi = point_offsets[n_problems];
+    const int row_hi = point_offsets[n_problems];
     if ((s = check_pnp_args(obj, img, row_hi, K)) != PH_OK)
         return s;
     if (!(confidence > 0 && confidence < 1))
@@ -1869,8 +1865,6 @@ ph_status ph_solvepnp_ransac_epnp_batched(const float *obj, const float *img,
             n_inliers[p] = k;
         found[p] = 1;
     }
-    (void)row_lo;
-    (void)max_n;
     return PH_OK;
 }
 
