@@ -464,6 +464,29 @@ def test_ten_million_train_rows_unsharded_and_eight_shards(posehip, nq):
         assert np.array_equal(true, dist[sel, r])
 
 
+@all_paths
+@pytest.mark.parametrize("nq,nt", [(20_000_000, 100), (70_000_000, 5), (3, 3_000_000)])
+def test_extreme_aspect_ratios(posehip, nq, nt):
+    """Tens of millions of queries against a handful of train rows, and the reverse: rows
+    generated on the GPU, the first and last 64 queries and 256 random ones against the
+    oracle (k = 2 + ratio), and no output row left unwritten."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    d_q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=g)
+    d_t = torch.randint(0, 256, (nt, 32), dtype=torch.uint8, device=dev, generator=g)
+    idx, dist, keep = gpu_knn_dev(posehip, d_q, d_t, 2, ratio=0.8)
+    assert int((idx == 777).sum().item()) == 0 and int((keep == 9).sum().item()) == 0
+    rows = torch.cat([torch.arange(0, min(nq, 64), device=dev),
+                      torch.arange(max(nq - 64, 0), nq, device=dev),
+                      torch.randint(0, nq, (256,), device=dev, generator=g)]).unique()
+    ri, rd = orc.knn(d_q[rows].cpu().numpy(), d_t.cpu().numpy(), 2, threads=8)
+    assert np.array_equal(idx[rows].cpu().numpy(), ri) and np.array_equal(dist[rows].cpu().numpy(), rd)
+    want = (ri[:, 1] >= 0) & (rd[:, 0].astype(np.float32) < np.float32(0.8) * rd[:, 1].astype(np.float32))
+    assert np.array_equal(keep[rows].cpu().numpy().astype(bool), want)
+
+
 def test_index_base_and_overflow_guard(posehip):
     q = datagen.random_descriptors(70, 91)
     t = datagen.random_descriptors(300, 92)
