@@ -69,3 +69,63 @@ def test_solvepnp_epnp_all_points():
     Ra, Rb = orc.rodrigues(np.ravel(rvec)), orc.rodrigues(np.ravel(r0))
     assert np.linalg.norm(Ra - Rb) / np.linalg.norm(Ra) <= 1e-9
     assert np.linalg.norm(np.ravel(tvec) - np.ravel(t0)) / np.linalg.norm(tvec) <= 1e-9
+
+
+def test_solvepnp_epnp_point_depth_decides_the_rounding_of_normalised_points():
+    """cv2.solvePnP on float32 points rounds undistortPoints' output to float, on float64
+    points it does not; solvePnPRansac's final solve is of the second kind.  Tight bounds:
+    the two oracle entry points differ by ~1e-8, so a mix-up fails here."""
+    obj, img, R, t, _ = datagen.pnp_scene(n=300, outlier_frac=0.0, seed=10)
+    K = np.ascontiguousarray(datagen.CAMERA_K)
+    for as_f64 in (False, True):
+        o, i = (obj.astype(np.float64), img.astype(np.float64)) if as_f64 else (obj, img)
+        ok, rvec, tvec = cv2.solvePnP(o, i, K, None, flags=cv2.SOLVEPNP_EPNP)
+        r0, t0 = orc.solvepnp_epnp(obj, img, K, points_as_f64=as_f64)
+        assert ok
+        assert np.abs(np.ravel(rvec) - r0).max() <= 1e-11 and np.abs(np.ravel(tvec) - t0).max() <= 1e-11
+    obj, img, R, t, _ = datagen.pnp_scene(n=400, outlier_frac=0.3, seed=12)
+    ok, rvec, tvec, inliers = cv2.solvePnPRansac(obj, img, K, None, iterationsCount=100,
+                                                 flags=cv2.SOLVEPNP_EPNP)
+    ok0, r0, t0, inl0, _ = orc.solvepnp_ransac(obj, img, K, iterations=100)
+    assert ok and ok0 and np.array_equal(np.ravel(inliers), inl0)
+    assert np.abs(np.ravel(rvec) - r0).max() <= 1e-11 and np.abs(np.ravel(tvec) - t0).max() <= 1e-11
+
+
+@pytest.mark.parametrize("angle", [0.0, 1e-9, 0.3, 1.0, 3.0, np.pi - 1e-9, np.pi])
+def test_rodrigues_both_ways(angle):
+    R = datagen.axis_angle_matrix((0.3, 1.0, 0.0), angle)
+    r_cv, _ = cv2.Rodrigues(R)
+    assert np.abs(np.ravel(r_cv) - orc.rodrigues(R)).max() <= 1e-14
+    R_cv, _ = cv2.Rodrigues(np.ravel(r_cv))
+    assert np.abs(R_cv - orc.rodrigues(np.ravel(r_cv))).max() <= 1e-15
+
+
+def test_inlier_rule_against_projectpoints():
+    """PnPRansacCallback::computeError: projectPoints stored as float, squared distance in
+    float, err <= (float)(thr*thr) -- rebuilt from cv2.projectPoints and compared with the
+    oracle's per-point errors and mask."""
+    obj, img, R, t, _ = datagen.pnp_scene(n=2000, outlier_frac=0.3, seed=3)
+    K = np.ascontiguousarray(datagen.CAMERA_K)
+    r = orc.rodrigues(R)
+    proj, _ = cv2.projectPoints(obj, r, t, K, None)
+    d = img - proj.reshape(-1, 2).astype(np.float32)
+    err = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)
+    good, mask, err0 = orc.count_inliers(obj, img, K, r, t, 8.0)
+    assert np.array_equal(err, err0)
+    assert np.array_equal(err <= np.float32(64.0), mask.astype(bool)) and good == int(mask.sum())
+
+
+def test_ransac_sample_sequence_through_the_iteration_count():
+    """The sampler cannot be read out of OpenCV directly; the iteration at which the adaptive
+    budget ends depends on every sample drawn before it, so equal inlier sets for several
+    budgets and scenes pin cv::RNG and getSubset together with the update rule."""
+    K = np.ascontiguousarray(datagen.CAMERA_K)
+    for seed in range(20, 30):
+        obj, img, R, t, _ = datagen.pnp_scene(n=150, outlier_frac=0.6, seed=seed)
+        for iters in (3, 10, 40, 400):
+            ok, rvec, tvec, inliers = cv2.solvePnPRansac(obj, img, K, None, iterationsCount=iters,
+                                                         flags=cv2.SOLVEPNP_EPNP)
+            ok0, r0, t0, inl0, _ = orc.solvepnp_ransac(obj, img, K, iterations=iters)
+            assert bool(ok) == bool(ok0)
+            if ok:
+                assert np.array_equal(np.ravel(inliers), inl0)
