@@ -109,3 +109,45 @@ def test_noalloc_degenerate_and_limits(posehip):
     st = lib.ph_knn_hamming256_noalloc_dev(big_q.data_ptr(), 10, big_t.data_ptr(), 10, 3, 0,
                                            out.data_ptr(), out.data_ptr(), None, 0.0, None)
     assert st == 1  # PH_ERR_INVALID_ARG: k
+
+
+@pytest.mark.parametrize("mode,nq,nt", [(1, 3000, 5000), (2, 20000, 30000)])
+def test_noalloc_under_graph_capture(posehip, mode, nq, nt):
+    """One of the callers the entry point is for: the call is captured into a HIP graph
+    (nothing may allocate or synchronise under capture), the graph is replayed on new
+    queries in the same buffers, and the replay equals the allocating entry point."""
+    import ctypes as C
+    import torch
+    lib = posehip.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    d_q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=g)
+    d_t = torch.randint(0, 256, (nt, 32), dtype=torch.uint8, device=dev, generator=g)
+    idx = torch.zeros((nq, 2), dtype=torch.int32, device=dev)
+    dist = torch.zeros_like(idx)
+    keep = torch.zeros(nq, dtype=torch.uint8, device=dev)
+    s = torch.cuda.Stream()
+    posehip.check(lib.ph_knn_set_path(mode))
+    try:
+        def call(stream_handle):
+            return lib.ph_knn_hamming256_noalloc_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, 2, 0,
+                                                     idx.data_ptr(), dist.data_ptr(), keep.data_ptr(),
+                                                     0.8, C.c_void_p(stream_handle))
+        posehip.check(call(s.cuda_stream))      # outside capture first: code objects get loaded
+        s.synchronize()
+        idx.zero_()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            status = call(torch.cuda.current_stream().cuda_stream)
+        posehip.check(status)
+        torch.cuda.synchronize()
+        assert int(idx.abs().sum().item()) == 0          # captured, not run
+        d_q.copy_(torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=g))
+        graph.replay()
+        torch.cuda.synchronize()
+        ri, rd, rk, _ = _call(posehip, "ph_knn_hamming256_dev", d_q, d_t, 2, 0, 0.8)
+        assert torch.equal(idx, ri) and torch.equal(dist, rd) and torch.equal(keep, rk)
+    finally:
+        lib.ph_knn_set_path(0)
