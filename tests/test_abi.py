@@ -48,3 +48,15 @@ def test_product_does_not_reference_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, fn)
+
+
+def test_only_test_code_loads_the_oracle():
+    """Outside tests/ the checker may be loaded by __graft_entry__.smoke() and by bench.py's
+    cpu_baseline legs only: no tool, example or header names its binding or its library."""
+    for top in ("tools", "examples", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for fn in files:
+                if fn.endswith((".py", ".sh", ".hip", ".h", ".cpp", ".hpp")):
+                    text = open(os.path.join(dirpath, fn)).read()
+                    for token in ("oracle_bind", "liboracle", "oracle/"):
+                        assert token not in text, (os.path.join(dirpath, fn), token)

@@ -96,7 +96,7 @@ def test_full_size_config_hypotheses_exact(posehip):
 
 
 def test_degenerate_sample_with_huge_translation(posehip):
-    """A case found by tools/fuzz_counts.py: a degenerate 5-point sample whose EPnP solve puts
+    """A case found by tests/tools/fuzz_counts.py: a degenerate 5-point sample whose EPnP solve puts
     the camera 1e38 units away.  The depth's reciprocal is then a denormal in fp32, which the
     scoring kernel's fp32 first pass must not rely on (it once read it as zero and counted a
     row at the image centre as an inlier).  Inputs and the oracle's outputs are kept in

@@ -2,13 +2,13 @@
 oracle: EVERY hypothesis' inlier count must equal the oracle's and every finite model agree to
 1e-11, over random scenes, correspondence counts, thresholds, outlier fractions and batch shapes
 (single problems and ragged batches).  Not part of the test suite:
-    python tools/fuzz_counts.py [seconds] [seed]"""
+    python tests/tools/fuzz_counts.py [seconds] [seed]"""
 import ctypes as C
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -1,11 +1,11 @@
 """Randomised differential run of the matcher entry points against the CPU oracle
 (shapes around the block, group and split boundaries, ragged and uniform frame batches,
 tie-heavy data).  Not part of the test suite; run it after kernel changes:
-    python tools/fuzz_matcher.py [seconds] [seed]
+    python tests/tools/fuzz_matcher.py [seconds] [seed]
 POSEHIP_KNN_PATH=matrix (or popcount) in the environment pins the distance kernel; by default
 the library picks by size, which at these shapes is mostly the popcount kernel."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import datagen, oracle_bind as orc

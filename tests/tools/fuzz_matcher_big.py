@@ -1,14 +1,14 @@
 """Randomised differential run of the k-NN entry point at LARGE shapes (hundreds to a
 thousand tiles per split, several splits, tie-heavy data) against the CPU oracle on sampled
-query rows; complements tools/fuzz_matcher.py, whose shapes are small.
-    python tools/fuzz_matcher_big.py [seconds] [seed]
+query rows; complements tests/tools/fuzz_matcher.py, whose shapes are small.
+    python tests/tools/fuzz_matcher_big.py [seconds] [seed]
 POSEHIP_KNN_PATH=matrix / popcount pins the distance kernel."""
 import ctypes as C
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

@@ -4,13 +4,13 @@ shapes (around the kernels' block sizes and up to tens of thousands of rows), de
 families (iid, tiny codebooks = ties everywhere, perturbed copies = true matches), both
 distance kernels, index bases, ragged frame batches, train shards + merge and the
 allocation-free entry point.  Not part of the test suite:
-    python tools/fuzz_matcher_dev.py [seconds] [seed]"""
+    python tests/tools/fuzz_matcher_dev.py [seconds] [seed]"""
 import ctypes as C
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

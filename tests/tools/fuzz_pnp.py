@@ -1,8 +1,8 @@
 """Randomised differential run of solvePnPRansac (batched and single) against the CPU oracle:
 random correspondence counts, outlier fractions, noise, iteration budgets, thresholds.
-Not part of the test suite:  python tools/fuzz_pnp.py [seconds] [seed]"""
+Not part of the test suite:  python tests/tools/fuzz_pnp.py [seconds] [seed]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import datagen, oracle_bind as orc

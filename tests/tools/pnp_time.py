@@ -1,6 +1,6 @@
 """Times the RANSAC-EPnP hypothesis kernel (4096 hypotheses x 2000 correspondences)."""
 import ctypes as C, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import datagen, oracle_bind as orc
