@@ -90,6 +90,27 @@ int orc_ransac_update_num_iters(double p, double ep, int model_points, int max_i
 
 /* ------------------------------------------------------------- Jacobi SVD */
 /*
+ * lapack.cpp's own hypot, a function template in namespace cv that the unqualified call in
+ * JacobiSVDImpl_ resolves to (it hides the C library's hypot there): the larger magnitude
+ * times sqrt(1 + ratio^2).  Not the C library's correctly rounded hypot: the two differ in
+ * the last bits, which the 5-point EPnP amplifies, so the form matters.
+ */
+static double cv_hypot(double a, double b)
+{
+    a = fabs(a);
+    b = fabs(b);
+    if (a > b) {
+        b /= a;
+        return a * sqrt(1 + b * b);
+    }
+    if (b > 0) {
+        a /= b;
+        return b * sqrt(1 + a * a);
+    }
+    return 0;
+}
+
+/*
  * JacobiSVDImpl_<double> of lapack.cpp: one-sided (Hestenes) Jacobi on the n
  * rows of At (each of length m), rotations accumulated in Vt (n x n).  On exit
  * row i of At is the i-th LEFT singular vector (unit length), W descending.
@@ -126,7 +147,7 @@ static void jacobi_svd(double *At, int astep, double *W_out, double *Vt, int vst
                 if (fabs(p) <= eps * sqrt(a * b))
                     continue;
                 p *= 2;
-                double beta = a - b, gamma = hypot(p, beta);
+                double beta = a - b, gamma = cv_hypot(p, beta);
                 if (beta < 0) {
                     double delta = (gamma - beta) * 0.5;
                     s = sqrt(delta / gamma);

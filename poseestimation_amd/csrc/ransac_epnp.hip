@@ -63,52 +63,22 @@ struct Rng {
     }
 };
 
-// sqrt(x*x + y*y) by N. Borges' corrected algorithm (one sqrt plus one
-// correction step on the larger/smaller operands), the method current C
-// libraries use for hypot; it returns the correctly rounded value in practice,
-// so the Jacobi rotations below round exactly like a host statement that calls
-// the C library's hypot.
-__device__ inline double hypot_kernel(double ax, double ay)
+// hypot as OpenCV's JacobiSVD computes it: lapack.cpp has a function template hypot of its own
+// in namespace cv, which the unqualified call in JacobiSVDImpl_ resolves to (it hides the C
+// library's): the larger magnitude times sqrt(1 + ratio^2).  Written with selects, so that
+// it is straight-line code; every lane performs exactly the division, product, sum, square
+// root and product of its own case:
+//   a = |a|, b = |b|;  a > b: b /= a, a * sqrt(1 + b*b);  else b > 0: a /= b, b * sqrt(1 + a*a);
+//   else 0.
+__device__ __forceinline__ double cv_hypot(double a, double b)
 {
-    double t1, t2;
-    double h = sqrt(ax * ax + ay * ay);
-    if (h <= 2.0 * ay) {
-        const double delta = h - ay;
-        t1 = ax * (2.0 * delta - ax);
-        t2 = (delta - 2.0 * (ax - ay)) * delta;
-    } else {
-        const double delta = h - ax;
-        t1 = 2.0 * delta * (ax - 2.0 * ay);
-        t2 = (4.0 * delta - ay) * ay + delta * delta;
-    }
-    h -= (t1 + t2) / (2.0 * h);
-    return h;
-}
-
-__device__ double hypot_cr(double x, double y)
-{
-    const double SCALE = 0x1p-600, LARGE_VAL = 0x1p+511, TINY_VAL = 0x1p-459, EPS = 0x1p-54;
-    if (!isfinite(x) || !isfinite(y)) {
-        if (isinf(x) || isinf(y))
-            return INFINITY;
-        return x + y;
-    }
-    x = fabs(x);
-    y = fabs(y);
-    const double ax = x < y ? y : x, ay = x < y ? x : y;
-    if (ax > LARGE_VAL) {
-        if (ay <= ax * EPS)
-            return ax + ay;
-        return hypot_kernel(ax * SCALE, ay * SCALE) / SCALE;
-    }
-    if (ay < TINY_VAL) {
-        if (ax >= ay / EPS)
-            return ax + ay;
-        return hypot_kernel(ax / SCALE, ay / SCALE) * SCALE;
-    }
-    if (ax >= ay / EPS)
-        return ax + ay;
-    return hypot_kernel(ax, ay);
+    a = fabs(a);
+    b = fabs(b);
+    const bool a_larger = a > b;
+    const double big = a_larger ? a : b, small = a_larger ? b : a;
+    const double q = small / big;
+    const double h = big * sqrt(1 + q * q);
+    return (a_larger || b > 0) ? h : 0.0;
 }
 
 // Rotation (c, s) of a Jacobi pair:
@@ -183,7 +153,7 @@ __device__ __forceinline__ bool jacobi_small_pair(LP<ST> At, LP<ST> W, LP<ST> Vt
     if (fabs(p) <= eps * sqrt(a * b))
         return false;
     p *= 2;
-    const double beta = a - b, gamma = hypot_cr(p, beta);
+    const double beta = a - b, gamma = cv_hypot(p, beta);
     jacobi_rotation(p, beta, gamma, c, s);
     a = b = 0;
 #pragma unroll
@@ -245,7 +215,7 @@ __device__ __forceinline__ bool jacobi_small_pair_half(LP<ST> At, LP<ST> W, LP<S
     if (fabs(p) <= eps * sqrt(a * b))
         return false;
     p *= 2;
-    const double beta = a - b, gamma = hypot_cr(p, beta);
+    const double beta = a - b, gamma = cv_hypot(p, beta);
     jacobi_rotation(p, beta, gamma, c, s);
     const double cv = second ? -s : c, cj = second ? c : s;
     const LP<ST> row = second ? Aj : Ai;
@@ -361,7 +331,7 @@ __device__ void jacobi_svd(LP<ST> At, int astep, LP<ST> W, LP<ST> Vt, int vstep,
                 if (fabs(p) <= eps * sqrt(a * b))
                     continue;
                 p *= 2;
-                const double beta = a - b, gamma = hypot_cr(p, beta);
+                const double beta = a - b, gamma = cv_hypot(p, beta);
                 jacobi_rotation(p, beta, gamma, c, s);
                 a = b = 0;
                 for (int k = 0; k < m; k++) {
@@ -497,7 +467,7 @@ __device__ __forceinline__ void jacobi_pair(LP<ST> At, LP<ST> W, JacobiRow<N> &r
     if (fabs(p) <= eps * sqrt(a * b))
         return;
     p *= 2;
-    const double beta = a - b, gamma = hypot_cr(p, beta);
+    const double beta = a - b, gamma = cv_hypot(p, beta);
     double c, s;
     jacobi_rotation(p, beta, gamma, c, s);
     a = b = 0;
@@ -518,11 +488,10 @@ __device__ __forceinline__ void jacobi_pair(LP<ST> At, LP<ST> W, JacobiRow<N> &r
 
 // The arithmetic of one pair without control flow, so that two of them can be issued
 // interleaved: every quantity is computed as in jacobi_pair and `rotate` says whether the
-// pair is past the convergence test; `plain` is false where hypot leaves its ordinary
-// range (non-finite, huge or tiny operands), which the caller hands to jacobi_pair.
+// pair is past the convergence test.
 template <int N> struct PairMath {
     double aj[N], nv[N], nj[N], na, nb, p, a, b;
-    bool rotate, plain;
+    bool rotate;
 };
 
 // Partner row, dot product and convergence test.
@@ -550,28 +519,7 @@ __device__ __forceinline__ void jacobi_pair_rotation(PairMath<N> &m, double &c, 
 {
     const double p = m.p * 2;
     const double beta = m.a - m.b;
-    // hypot_cr(p, beta) on its ordinary range
-    const double LARGE_VAL = 0x1p+511, TINY_VAL = 0x1p-459;
-    const double x = fabs(p), y = fabs(beta);
-    const double ax = x < y ? y : x, ay = x < y ? x : y;
-    const bool negligible = ax >= ay * 0x1p54; // == ay / 2^-54, exact
-    m.plain = (ax <= LARGE_VAL) & ((ay >= TINY_VAL) | negligible); // no short-circuit branches
-    double h = sqrt(ax * ax + ay * ay);
-    {
-        // both forms of hypot_kernel's correction, computed unconditionally (KEEP stops
-        // the compiler from sinking them into conditional regions, which would end the
-        // straight-line code the interleaving needs), then selected per lane
-        const bool near = h <= 2.0 * ay;
-        const double dn = h - ay, df = h - ax;
-        double t1n = ax * (2.0 * dn - ax), t2n = (dn - 2.0 * (ax - ay)) * dn;
-        double t1f = 2.0 * df * (ax - 2.0 * ay), t2f = (4.0 * df - ay) * ay + df * df;
-        KEEP(t1n); KEEP(t2n); KEEP(t1f); KEEP(t2f);
-        const double t1 = near ? t1n : t1f, t2 = near ? t2n : t2f;
-        h -= (t1 + t2) / (2.0 * h);
-    }
-    double sum = ax + ay;
-    KEEP(h); KEEP(sum);
-    const double gamma = negligible ? sum : h;
+    const double gamma = cv_hypot(p, beta);
     jacobi_rotation(p, beta, gamma, c, s);
 }
 
@@ -627,12 +575,6 @@ __device__ __forceinline__ void jacobi_pair2(LP<ST> At, LP<ST> W, JacobiRow<N> &
         return; // both pairs converged in every lane
     jacobi_pair_math<N>(ra, ma);
     jacobi_pair_math<N>(rb, mb);
-    const bool odd = (ma.rotate & !ma.plain) | (mb.rotate & !mb.plain);
-    if (__builtin_amdgcn_ballot_w64(odd) != 0) { // some lane needs hypot's special ranges
-        jacobi_pair<ST, N>(At, W, ra, ja, eps, changed);
-        jacobi_pair<ST, N>(At, W, rb, jb, eps, changed);
-        return;
-    }
     jacobi_pair_commit<ST, N>(At, W, ra, ja, ma, changed);
     jacobi_pair_commit<ST, N>(At, W, rb, jb, mb, changed);
 }
@@ -650,11 +592,6 @@ __device__ __forceinline__ bool jacobi_pair_lds(LP<ST> At, LP<ST> W, int i, int 
     if (__builtin_amdgcn_ballot_w64(m.rotate) == 0)
         return false;
     jacobi_pair_math<N>(r, m);
-    if (__builtin_amdgcn_ballot_w64(m.rotate & !m.plain) != 0) { // hypot's special ranges
-        jacobi_pair<ST, N>(At, W, r, j, eps, r.dirty);
-        r.store(Ai, W[i]);
-        return r.dirty;
-    }
     if (m.rotate) {
 #pragma unroll
         for (int k = 0; k < N; k++) {
@@ -685,11 +622,6 @@ __device__ __forceinline__ bool jacobi_pair_lds_half(LP<ST> At, LP<ST> W, int i,
         return false;
     double c, s;
     jacobi_pair_rotation<N>(m, c, s);
-    if (__builtin_amdgcn_ballot_w64(m.rotate & !m.plain) != 0) { // hypot's special ranges:
-        jacobi_pair<ST, N>(At, W, r, j, eps, r.dirty); // both lanes do the whole pair alike
-        r.store(Ai, W[i]);
-        return r.dirty;
-    }
     const double cv = second ? -s : c, cj = second ? c : s;
     double out[N], norm2 = 0;
 #pragma unroll

@@ -5,7 +5,7 @@
 // the GPU as well; the lanes that help a hypothesis repeat some operations, which is
 // overhead, not algorithmic work.
 //
-// Convention: add / sub / mul / div / sqrt count one FLOP each, hypot / acos / sin / cos /
+// Convention: add / sub / mul / div / sqrt count one FLOP each, acos / sin / cos /
 // pow / log one each as well (listed separately); comparisons, fabs, negation and
 // conversions count zero.  The oracle is built without contraction, so there is no fma.
 //
@@ -49,7 +49,6 @@ static inline CD operator/(CD a, CD b) { g_n.div++; return CD(a.v / b.v); }
 CD_CMP(<) CD_CMP(<=) CD_CMP(>) CD_CMP(>=) CD_CMP(==) CD_CMP(!=)
 static inline CD fabs(CD a) { return CD(fabs(a.v)); }
 static inline CD sqrt(CD a) { g_n.sqrt_++; return CD(sqrt(a.v)); }
-static inline CD hypot(CD a, CD b) { g_n.trans++; return CD(hypot(a.v, b.v)); }
 static inline CD acos(CD a) { g_n.trans++; return CD(acos(a.v)); }
 static inline CD sin(CD a) { g_n.trans++; return CD(sin(a.v)); }
 static inline CD cos(CD a) { g_n.trans++; return CD(cos(a.v)); }

@@ -57,7 +57,7 @@ if __name__ == "__main__":
         res = count()
         res["what"] = ("fp64 operations per hypothesis, mean over cv::RNG's first 4096 samples of "
                        "datagen.pnp_scene(n=2000, outlier_frac=0.3, seed=3) (bench.py's problem 0); "
-                       "add/sub/mul/div/sqrt and hypot/acos/sin/cos one FLOP each, compares zero; "
+                       "add/sub/mul/div/sqrt and acos/sin/cos one FLOP each, compares zero; "
                        "scoring adds 5 fp32 operations per correspondence")
         json.dump(res, open(COMMITTED, "w"), indent=1)
         print(json.dumps(res))

@@ -78,6 +78,19 @@ def test_round_counts():
     assert many == 12 * 10 + 9
 
 
+def cv_hypot(a, b):
+    """hypot as OpenCV's JacobiSVD computes it (lapack.cpp's own template), rounded one
+    operation at a time."""
+    a, b = abs(a), abs(b)
+    if a > b:
+        b /= a
+        return a * math.sqrt(1 + b * b)
+    if b > 0:
+        a /= b
+        return b * math.sqrt(1 + a * a)
+    return 0.0
+
+
 def pair(A, W, i, j, eps):
     """One pair on rows i, j of A (squared norms W); the arithmetic of the fixed-size pair
     in ransac_epnp.hip in float64, products and sums rounded one by one."""
@@ -88,7 +101,7 @@ def pair(A, W, i, j, eps):
         return False
     p *= 2.0
     beta = a - b
-    gamma = math.hypot(p, beta)
+    gamma = cv_hypot(p, beta)
     if beta < 0:
         s = math.sqrt((gamma - beta) * 0.5 / gamma)
         c = p / (gamma * s * 2)
@@ -233,7 +246,7 @@ def pair_by_two_lanes(A, W, i, j, eps):
         return False
     p *= 2.0
     beta = a - b
-    gamma = math.hypot(p, beta)
+    gamma = cv_hypot(p, beta)
     if beta < 0:
         s = math.sqrt((gamma - beta) * 0.5 / gamma)
         c = p / (gamma * s * 2)

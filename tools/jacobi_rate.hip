@@ -58,7 +58,7 @@ __device__ __forceinline__ void reg_pair(double (&A)[12][12], double (&W)[12], d
         return;
     if (rotate) {
         p *= 2;
-        const double beta = a - b, gamma = hypot_cr(p, beta);
+        const double beta = a - b, gamma = cv_hypot(p, beta);
         double c, s;
         jacobi_rotation(p, beta, gamma, c, s);
         a = b = 0;
