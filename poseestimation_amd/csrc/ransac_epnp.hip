@@ -2406,8 +2406,12 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
     // iterations): three waves per 8 hypotheses, one per candidate; per 4 hypotheses where
     // that still fits (16 lanes per hypothesis: two lanes per Jacobi pair).  Measured, solve
     // only: 100 hypotheses 0.25 ms (one wave per 8) -> 0.21 -> 0.19 ms, 2048 0.25 -> 0.22 ms.
+    // Up to four hypotheses per SIMD (4096 on this chip) a wave takes 4, so that every SIMD has
+    // a wave and a hypothesis 16 lanes: 4096 hypotheses x 2000 rows, solve + score, 0.237 ->
+    // 0.224 ms per call against 8 per wave on half the SIMDs.
     const bool lone4 = n_hyp <= n_cus * 4;
     const bool lone = n_hyp <= n_cus * 8;
+    const bool quad = n_hyp <= n_cus * 4 * 4;
     const bool tiny = n_hyp <= n_cus * 4 * 8;
     const bool small = n_hyp <= n_cus * 4 * 16;
     // A large batch goes down in rounds of one GPU-full of solves; the scoring of a
@@ -2434,6 +2438,9 @@ hipError_t ransac_hypotheses_launch(const float *d_obj, const float *d_img, int 
         else if (lone)
             e = launch_solve3<8>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
                                  d_models, stream);
+        else if (quad)
+            e = launch_solve<4>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
+                                d_models, stream);
         else if (tiny)
             e = launch_solve<8>(d_obj, d_img, K, d_subsets, d_begins, hyp_per_problem, h0, h1,
                                 d_models, stream);

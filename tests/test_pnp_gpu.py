@@ -369,7 +369,7 @@ def test_degenerate_samples_agree_with_oracle(posehip):
 
 def test_every_solve_kernel_gives_the_same_models(posehip):
     """The library picks the solve kernel by the number of hypotheses in the call (three
-    waves per 4 or per 8 hypotheses for a lone small call, one wave per 8, 16 or 32
+    waves per 4 or per 8 hypotheses for a lone small call, one wave per 4, 8, 16 or 32
     beyond); every one performs the sequential statement's operations in its order, so a
     hypothesis must get bit for bit the same model and count whatever the call's size, the
     degenerate samples' NaNs included, and the oracle's counts on a sample."""
@@ -377,7 +377,7 @@ def test_every_solve_kernel_gives_the_same_models(posehip):
     obj[:40] = obj[0]                      # some degenerate samples
     sub = orc.ransac_subsets(400, 17000)
     m_ref, c_ref = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, sub)       # 32 per wave
-    for h in (3, 100, 1021, 1024, 1025, 2048, 2049, 8192, 8193, 16384):
+    for h in (3, 100, 1021, 1024, 1025, 2048, 2049, 4096, 4097, 8192, 8193, 16384):
         m, c = gpu_hypotheses(posehip, obj, img, datagen.CAMERA_K, sub[:h])
         assert np.array_equal(c, c_ref[:h]), h
         assert np.array_equal(m.view(np.uint64), m_ref[:h].view(np.uint64)), h
