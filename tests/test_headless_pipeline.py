@@ -45,11 +45,19 @@ def _dmatches(a):
             for r in a]
 
 
-def test_headless_pipeline_is_built():
-    assert os.path.exists(EXE), "run __graft_entry__.build() first"
+def test_headless_pipeline_builds_with_plain_gxx(tmp_path):
+    """No hipcc, no torch, no OpenCV: g++ on the shim and the C ABI, as __graft_entry__.build()
+    compiles it in-tree."""
+    lib_dir = os.path.join(ROOT, "poseestimation_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread",
+                           os.path.join(ROOT, "examples", "headless_pipeline.cpp"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + lib_dir, "-lposehip",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib",
+                           "-o", str(tmp_path / "headless_pipeline")])
 
 
 def _run(args, tmp_path):
+    assert os.path.exists(EXE), "run __graft_entry__.build() first"
     dump = tmp_path / "frames.bin"
     out = subprocess.run([EXE] + args + ["--dump", str(dump)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
