@@ -83,8 +83,11 @@ ph_status ph_match_hamming256(const uint8_t *query, int nq, size_t q_step, const
                               int nt, size_t t_step, ph_dmatch *out, int *n_out);
 
 /* match(query, train) of a matcher built with crossCheck=true:
- * src/orb_feature_matching/matcher.py:18,21.  out holds up to nq entries in
- * ascending queryIdx; queries without a surviving pair are dropped. */
+ * src/orb_feature_matching/matcher.py:18,21.  A pair (q, t) is returned iff t is q's
+ * nearest train row AND q is t's nearest query row, each with the lowest-index rule on
+ * ties (cv::batchDistance's crosscheck branch since OpenCV 3.4.2 / 4.0, pinned by its
+ * regression test Features2d_DMatch.issue_11855).  out holds up to nq entries in
+ * ascending queryIdx; queries without a consistent pair are dropped. */
 ph_status ph_match_crosscheck_hamming256(const uint8_t *query, int nq, size_t q_step,
                                          const uint8_t *train, int nt, size_t t_step,
                                          ph_dmatch *out, int *n_out);
@@ -213,17 +216,25 @@ ph_status ph_match_crosscheck_hamming256_dev(const void *d_query, int64_t nq, co
 
 /* The cross-check matcher when the train set is sharded over GPUs (no counterpart in the
  * reference, which is single-process; the arithmetic is that of
- * src/orb_feature_matching/matcher.py:18,21).  Every train row's nearest query is found
- * among ALL queries, so that pass is local to the shard that owns the row; this call
- * returns, per query, the best (distance, train index) among the rows of THIS shard that
- * chose it, with train_index_base added to the index (PH_NO_MATCH_* where no row of the
- * shard chose the query).  The cross-check result over the whole train set is the
- * per-query minimum by (distance, global index) over the shards: all-gather the lists and
- * fold them with ph_knn_merge_dev(k = 1). */
+ * src/orb_feature_matching/matcher.py:18,21).  With the queries replicated, every train
+ * row's nearest query is known to the shard that owns the row.  This call returns, per
+ * query, its nearest train row WITHIN this shard as a candidate for ph_knn_merge_dev:
+ * d_out_idx[q] = 2 * (index + train_index_base) + flag, flag = 1 iff q is that row's
+ * nearest query (PH_NO_MATCH_* for a shard without rows); indices are therefore limited
+ * to 2^30.  Over the whole train set: all-gather the lists, fold them with
+ * ph_knn_merge_dev(k = 1) -- the smallest (distance, index) wins and its flag rides
+ * along -- and unpack with ph_match_crosscheck_unpack_dev. */
 ph_status ph_match_crosscheck_hamming256_shard_dev(const void *d_query, int64_t nq,
                                                    const void *d_train_shard, int64_t nt,
                                                    int32_t train_index_base, int32_t *d_out_idx,
                                                    int32_t *d_out_dist, void *stream);
+
+/* Last step of the sharded cross-check (no counterpart in the reference): in place,
+ * d_idx[q] = 2 * index + flag becomes index where the flag is set and PH_NO_MATCH_IDX /
+ * PH_NO_MATCH_DIST where it is not (the query's nearest train row has another nearest
+ * query). */
+ph_status ph_match_crosscheck_unpack_dev(int32_t *d_idx, int32_t *d_dist, int64_t nq,
+                                         void *stream);
 
 /* ---- RANSAC-EPnP pose ------------------------------------------------------- */
 /* Replaces cv::solvePnPRansac(obj, img, K, noArray(), rvec, tvec, false,

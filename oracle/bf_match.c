@@ -14,7 +14,8 @@
  * This file restates that published algorithm.  PARITY UNPINNED: the reference
  * holds no test, golden vector or fixture for this path and OpenCV is not
  * installable here, so the restatement is pinned only by hand-computed
- * known-answer cases in tests/.
+ * known-answer cases in tests/ and by the one vector of OpenCV's own test suite for
+ * this path (the cross-check regression test, see orc_match_crosscheck).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this file's shared object; the product library never does.
@@ -173,14 +174,20 @@ int orc_match(const uint8_t *q, int nq, size_t q_step, const uint8_t *t, int nt,
 }
 
 /*
- * match(query, train) with crossCheck=true (BFMatcher::knnMatchImpl, K==1):
+ * match(query, train) with crossCheck=true (BFMatcher::knnMatchImpl with K == 1 hands the
+ * flag to cv::batchDistance, whose crosscheck branch runs BOTH 1-NN searches):
  *   1. dist[q]=INT_MAX, nidx[q]=-1 for every query;
- *   2. 1-NN with roles swapped: every TRAIN row finds its nearest QUERY row
- *      (lowest query index on ties);
- *   3. for train i ascending: q=tidx[i]; if (tdist[i] < dist[q]) take it;
- *   4. emit (q, nidx[q], dist[q]) for queries with nidx[q]>=0, ascending q.
- * This is NOT a mutual-nearest-neighbour test: a query is paired with the
- * closest train row among the train rows whose nearest query it is.
+ *   2. tidx[i] / tdist[i]: every TRAIN row's nearest QUERY row (roles swapped; lowest
+ *      query index on ties);
+ *   3. sidx[q]: every QUERY row's nearest TRAIN row (lowest train index on ties);
+ *   4. for train i ascending: q=tidx[i]; if (tdist[i] < dist[q] && sidx[q] == i) take it;
+ *   5. emit (q, nidx[q], dist[q]) for queries with nidx[q]>=0, ascending q.
+ * A pair survives iff each row is the other's nearest neighbour ("the BFMatcher will only
+ * return consistent pairs").  OpenCV before 3.4.2 / 4.0 lacked step 3 and its condition
+ * (a query was paired with the closest train row among those whose nearest query it was,
+ * which is not mutual); the library's regression test Features2d_DMatch.issue_11855
+ * (modules/features2d/test/test_matchers_algorithmic.cpp) pins the mutual form, and its
+ * vector is part of tests/golden/matcher_kat.json.  The reference names OpenCV 4.6.0.
  * Returns the number of matches written (out must hold nq).
  */
 int orc_match_crosscheck(const uint8_t *q, int nq, size_t q_step, const uint8_t *t, int nt,
@@ -190,19 +197,23 @@ int orc_match_crosscheck(const uint8_t *q, int nq, size_t q_step, const uint8_t 
         return 0;
     int32_t *dist = (int32_t *)malloc(sizeof(int32_t) * (size_t)nq);
     int32_t *nidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)nq);
-    if (!dist || !nidx) {
+    int32_t *sidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)nq);
+    if (!dist || !nidx || !sidx) {
         free(dist);
         free(nidx);
+        free(sidx);
         return -1;
     }
     for (int i = 0; i < nq; i++) {
+        int32_t sd;
         dist[i] = INT_MAX;
         nidx[i] = -1;
+        knn_one_query(q + (size_t)i * q_step, t, nt, t_step, 1, &sidx[i], &sd);
     }
     for (int i = 0; i < nt; i++) {
         int32_t tq, td;
         knn_one_query(t + (size_t)i * t_step, q, nq, q_step, 1, &tq, &td);
-        if (tq >= 0 && td < dist[tq]) {
+        if (tq >= 0 && td < dist[tq] && sidx[tq] == i) {
             dist[tq] = td;
             nidx[tq] = i;
         }
@@ -219,6 +230,7 @@ int orc_match_crosscheck(const uint8_t *q, int nq, size_t q_step, const uint8_t 
     }
     free(dist);
     free(nidx);
+    free(sidx);
     return n;
 }
 

@@ -75,6 +75,7 @@ SIGNATURES = {
     "ph_match_crosscheck_hamming256_shard_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p,
                                                            C.c_int64, C.c_int32, C.c_void_p,
                                                            C.c_void_p, C.c_void_p]),
+    "ph_match_crosscheck_unpack_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ph_stream_synchronize": (C.c_int, [C.c_void_p]),
     "ph_solvepnp_ransac_epnp": (C.c_int, [_f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_float,
                                           C.c_double, C.c_uint64, _f64p, _f64p, _i32p, _intp,

@@ -76,20 +76,28 @@ hipError_t knn_merge_shards_launch(const int32_t *d_cand_idx, const int32_t *d_c
                                    int32_t *d_out_dist, uint8_t *d_keep, float ratio,
                                    hipStream_t stream);
 
-// index_base is added to every emitted train index (a shard of a larger train set).
-hipError_t crosscheck_resolve_launch(const int32_t *d_tidx, const int32_t *d_tdist, int64_t nt,
-                                     int64_t nq, unsigned long long *d_best, int32_t *d_out_idx,
+// Cross-check resolve.  d_sidx / d_sdist: every query row's nearest train row and its distance;
+// d_tidx: every train row's nearest query row.  Query q keeps (d_sidx[q] + index_base,
+// d_sdist[q]) iff d_tidx[d_sidx[q]] == q, else (-1, INT_MAX).  packed (a shard of a larger
+// train set, whose result still has to meet the other shards'): every query keeps its
+// candidate, the index as 2 * (d_sidx[q] + index_base) + (1 iff d_tidx[d_sidx[q]] == q).
+hipError_t crosscheck_resolve_launch(const int32_t *d_sidx, const int32_t *d_sdist,
+                                     const int32_t *d_tidx, int64_t nq, int32_t *d_out_idx,
                                      int32_t *d_out_dist, hipStream_t stream,
-                                     int32_t index_base = 0);
+                                     int32_t index_base = 0, bool packed = false);
 
-// The same for a batch of frames: d_tidx / d_tdist indexed by train row of the whole
-// buffer (frame-local query indices), outputs by query row (frame-local train indices);
-// query rows [row_begin, row_end) are written.
-hipError_t crosscheck_resolve_frames_launch(const int32_t *d_tidx, const int32_t *d_tdist,
-                                            const int32_t *d_q_off, const int32_t *d_t_off,
-                                            int n_frames, int64_t max_nt, int64_t row_begin,
-                                            int64_t row_end, unsigned long long *d_best,
+// The same for a batch of frames: d_sidx / d_sdist indexed by query row of the whole buffer
+// (frame-local train indices), d_tidx by train row of the whole buffer (frame-local query
+// indices); outputs by query row (frame-local train indices).
+hipError_t crosscheck_resolve_frames_launch(const int32_t *d_sidx, const int32_t *d_sdist,
+                                            const int32_t *d_tidx, const int32_t *d_q_off,
+                                            const int32_t *d_t_off, int n_frames, int64_t max_nq,
                                             int32_t *d_out_idx, int32_t *d_out_dist,
                                             hipStream_t stream);
+
+// Unpacks merged shard candidates of the cross-check in place: idx = 2 * index + flag
+// becomes index where the flag is set, (-1, INT_MAX) where it is not.
+hipError_t crosscheck_unpack_launch(int32_t *d_idx, int32_t *d_dist, int64_t nq,
+                                    hipStream_t stream);
 
 } // namespace posehip

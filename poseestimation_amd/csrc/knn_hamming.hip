@@ -449,64 +449,62 @@ __global__ __launch_bounds__(256) void knn_merge_shards_kernel(
 }
 
 // ---- cross-check resolve -----------------------------------------------------
-// Step 3 of BFMatcher's cross-check: for train i ascending,
-//   q = tidx[i]; if (tdist[i] < dist[q]) { dist[q] = tdist[i]; nidx[q] = i; }
-// i.e. per query the minimum of (tdist, i) over the train rows that chose it:
-// an order-independent 64-bit atomic min.
-__global__ __launch_bounds__(256) void cc_init_kernel(unsigned long long *__restrict__ best,
-                                                      int64_t nq)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < nq)
-        best[i] = ~0ull;
-}
-
-__global__ __launch_bounds__(256) void cc_scatter_kernel(const int32_t *__restrict__ tidx,
-                                                         const int32_t *__restrict__ tdist,
-                                                         int64_t nt,
-                                                         unsigned long long *__restrict__ best)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nt)
-        return;
-    const int32_t q = tidx[i];
-    if (q < 0)
-        return;
-    const unsigned long long key = ((unsigned long long)(uint32_t)tdist[i] << 32) | (uint32_t)i;
-    atomicMin(&best[q], key);
-}
-
-__global__ __launch_bounds__(256) void cc_finalize_kernel(
-    const unsigned long long *__restrict__ best, int64_t nq, int32_t index_base,
+// cv::batchDistance with crosscheck = true runs both 1-NN searches and, for train i
+// ascending, q = tidx[i]:
+//   if (tdist[i] < dist[q] && sidx[q] == i) { dist[q] = tdist[i]; nidx[q] = i; }
+// At most one train row passes for a query -- its own nearest row sidx[q], if that row's
+// nearest query is q --, so the loop over the train rows is a gather over the queries:
+// query q keeps (sidx[q], sdist[q]) iff tidx[sidx[q]] == q.
+__global__ __launch_bounds__(256) void cc_mutual_kernel(
+    const int32_t *__restrict__ sidx, const int32_t *__restrict__ sdist,
+    const int32_t *__restrict__ tidx, int64_t nq, int32_t index_base, bool packed,
     int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nq)
         return;
-    const unsigned long long b = best[i];
-    out_idx[i] = b == ~0ull ? -1 : (int32_t)(uint32_t)b + index_base;
-    out_dist[i] = b == ~0ull ? 0x7FFFFFFF : (int32_t)(b >> 32);
+    const int32_t t = sidx[i];
+    const bool mutual = t >= 0 && tidx[t] == (int32_t)i;
+    if (packed) { // a shard's candidate: the flag rides below the index through the merge
+        out_idx[i] = t < 0 ? -1 : (int32_t)(((uint32_t)(t + index_base) << 1) | (mutual ? 1u : 0u));
+        out_dist[i] = t < 0 ? 0x7FFFFFFF : sdist[i];
+    } else {
+        out_idx[i] = mutual ? t + index_base : -1;
+        out_dist[i] = mutual ? sdist[i] : 0x7FFFFFFF;
+    }
 }
 
-// The scatter step for a batch of frames (grid.y = frame): tidx / tdist are indexed by
-// train row of the whole buffer and hold query indices local to the frame; best is
-// indexed by query row of the whole buffer and receives frame-local train indices.
-__global__ __launch_bounds__(256) void cc_scatter_frames_kernel(
-    const int32_t *__restrict__ tidx, const int32_t *__restrict__ tdist,
-    const int32_t *__restrict__ q_off, const int32_t *__restrict__ t_off,
-    unsigned long long *__restrict__ best)
+// The same for a batch of frames (grid.y = frame): sidx / sdist and the outputs are
+// indexed by query row of the whole buffer and hold frame-local train indices, tidx is
+// indexed by train row of the whole buffer and holds frame-local query indices.
+__global__ __launch_bounds__(256) void cc_mutual_frames_kernel(
+    const int32_t *__restrict__ sidx, const int32_t *__restrict__ sdist,
+    const int32_t *__restrict__ tidx, const int32_t *__restrict__ q_off,
+    const int32_t *__restrict__ t_off, int32_t *__restrict__ out_idx,
+    int32_t *__restrict__ out_dist)
 {
     const int f = blockIdx.y;
-    const int64_t t0 = t_off[f], nt = t_off[f + 1] - t0;
+    const int64_t q0 = q_off[f], nq = q_off[f + 1] - q0;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nt)
+    if (i >= nq)
         return;
-    const int32_t q = tidx[t0 + i];
-    if (q < 0)
+    const int32_t t = sidx[q0 + i];
+    const bool mutual = t >= 0 && tidx[(int64_t)t_off[f] + t] == (int32_t)i;
+    out_idx[q0 + i] = mutual ? t : -1;
+    out_dist[q0 + i] = mutual ? sdist[q0 + i] : 0x7FFFFFFF;
+}
+
+__global__ __launch_bounds__(256) void cc_unpack_kernel(int32_t *__restrict__ idx,
+                                                        int32_t *__restrict__ dist, int64_t nq)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq)
         return;
-    const unsigned long long key =
-        ((unsigned long long)(uint32_t)tdist[t0 + i] << 32) | (uint32_t)i;
-    atomicMin(&best[(int64_t)q_off[f] + q], key);
+    const int32_t p = idx[i];
+    const bool keep = p >= 0 && (p & 1);
+    idx[i] = keep ? p >> 1 : -1;
+    if (!keep)
+        dist[i] = 0x7FFFFFFF;
 }
 
 // ---- launchers ---------------------------------------------------------------
@@ -768,34 +766,36 @@ hipError_t knn_merge_shards_launch(const int32_t *d_cand_idx, const int32_t *d_c
     return hipGetLastError();
 }
 
-hipError_t crosscheck_resolve_launch(const int32_t *d_tidx, const int32_t *d_tdist, int64_t nt,
-                                     int64_t nq, unsigned long long *d_best, int32_t *d_out_idx,
-                                     int32_t *d_out_dist, hipStream_t stream, int32_t index_base)
+hipError_t crosscheck_resolve_launch(const int32_t *d_sidx, const int32_t *d_sdist,
+                                     const int32_t *d_tidx, int64_t nq, int32_t *d_out_idx,
+                                     int32_t *d_out_dist, hipStream_t stream, int32_t index_base,
+                                     bool packed)
 {
-    cc_init_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, stream>>>(d_best, nq);
-    cc_scatter_kernel<<<(unsigned)((nt + 255) / 256), 256, 0, stream>>>(d_tidx, d_tdist, nt,
-                                                                         d_best);
-    cc_finalize_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, stream>>>(d_best, nq, index_base,
-                                                                          d_out_idx, d_out_dist);
+    cc_mutual_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, stream>>>(
+        d_sidx, d_sdist, d_tidx, nq, index_base, packed, d_out_idx, d_out_dist);
     return hipGetLastError();
 }
 
-hipError_t crosscheck_resolve_frames_launch(const int32_t *d_tidx, const int32_t *d_tdist,
-                                            const int32_t *d_q_off, const int32_t *d_t_off,
-                                            int n_frames, int64_t max_nt, int64_t row_begin,
-                                            int64_t row_end, unsigned long long *d_best,
+hipError_t crosscheck_resolve_frames_launch(const int32_t *d_sidx, const int32_t *d_sdist,
+                                            const int32_t *d_tidx, const int32_t *d_q_off,
+                                            const int32_t *d_t_off, int n_frames, int64_t max_nq,
                                             int32_t *d_out_idx, int32_t *d_out_dist,
                                             hipStream_t stream)
 {
-    const int64_t rows = row_end - row_begin;
-    if (rows <= 0)
+    if (max_nq <= 0 || n_frames <= 0)
         return hipSuccess;
-    cc_init_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, stream>>>(d_best + row_begin, rows);
-    if (max_nt > 0)
-        cc_scatter_frames_kernel<<<dim3((unsigned)((max_nt + 255) / 256), (unsigned)n_frames), 256,
-                                   0, stream>>>(d_tidx, d_tdist, d_q_off, d_t_off, d_best);
-    cc_finalize_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, stream>>>(
-        d_best + row_begin, rows, 0, d_out_idx + row_begin, d_out_dist + row_begin);
+    cc_mutual_frames_kernel<<<dim3((unsigned)((max_nq + 255) / 256), (unsigned)n_frames), 256, 0,
+                              stream>>>(d_sidx, d_sdist, d_tidx, d_q_off, d_t_off, d_out_idx,
+                                        d_out_dist);
+    return hipGetLastError();
+}
+
+hipError_t crosscheck_unpack_launch(int32_t *d_idx, int32_t *d_dist, int64_t nq,
+                                    hipStream_t stream)
+{
+    if (nq <= 0)
+        return hipSuccess;
+    cc_unpack_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, stream>>>(d_idx, d_dist, nq);
     return hipGetLastError();
 }
 

@@ -134,7 +134,7 @@ struct Context {
     DevBuf part;   // per-split keys of the distance kernel
     DevBuf part2;  // same, for the swapped pass of the cross-check
     DevBuf xt;     // FP4 image of the train rows (matrix-core path)
-    DevBuf best;   // cross-check per-query 64-bit keys
+    DevBuf best;   // cross-check per-query nearest train index | distance
     DevBuf tmp_i;  // cross-check per-train nearest query index
     DevBuf tmp_d;  // cross-check per-train nearest query distance
     DevBuf d_in;            // host entry points: device copy of the gathered inputs
@@ -301,8 +301,13 @@ ph_status knn_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t n
     return PH_OK;
 }
 
+// Cross-check match on device buffers (the caller holds g_mu): both 1-NN searches, then the
+// gather that keeps a query's nearest train row iff the query is that row's nearest query.
+// packed: the result is one shard's candidate list for ph_knn_merge_dev (see
+// crosscheck_resolve_launch).
 ph_status crosscheck_dev_locked(const void *d_q, int64_t nq, const void *d_t, int64_t nt,
-                                int32_t *d_idx, int32_t *d_dist, hipStream_t st, int32_t base = 0)
+                                int32_t *d_idx, int32_t *d_dist, hipStream_t st, int32_t base = 0,
+                                bool packed = false)
 {
     if (nq == 0)
         return PH_OK;
@@ -317,15 +322,19 @@ ph_status crosscheck_dev_locked(const void *d_q, int64_t nq, const void *d_t, in
         return gs;
     PH_HIP(g_ctx.tmp_i.reserve((size_t)nt * sizeof(int32_t)));
     PH_HIP(g_ctx.tmp_d.reserve((size_t)nt * sizeof(int32_t)));
-    PH_HIP(g_ctx.best.reserve((size_t)nq * sizeof(unsigned long long)));
-    // Roles swapped: every train row finds its nearest query row.
-    ph_status s = knn_dev_locked(d_t, nt, d_q, nq, 1, 0, (int32_t *)g_ctx.tmp_i.p,
-                                 (int32_t *)g_ctx.tmp_d.p, nullptr, 0.f, g_ctx.part2, st);
+    PH_HIP(g_ctx.best.reserve((size_t)nq * 2 * sizeof(int32_t)));
+    int32_t *sidx = (int32_t *)g_ctx.best.p, *sdist = sidx + nq;
+    // every query row's nearest train row ...
+    ph_status s = knn_dev_locked(d_q, nq, d_t, nt, 1, 0, sidx, sdist, nullptr, 0.f, g_ctx.part, st);
     if (s != PH_OK)
         return s;
-    PH_HIP(crosscheck_resolve_launch((const int32_t *)g_ctx.tmp_i.p, (const int32_t *)g_ctx.tmp_d.p,
-                                     nt, nq, (unsigned long long *)g_ctx.best.p, d_idx, d_dist,
-                                     st, base));
+    // ... and, roles swapped, every train row's nearest query row
+    s = knn_dev_locked(d_t, nt, d_q, nq, 1, 0, (int32_t *)g_ctx.tmp_i.p, (int32_t *)g_ctx.tmp_d.p,
+                       nullptr, 0.f, g_ctx.part2, st);
+    if (s != PH_OK)
+        return s;
+    PH_HIP(crosscheck_resolve_launch(sidx, sdist, (const int32_t *)g_ctx.tmp_i.p, nq, d_idx, d_dist,
+                                     st, base, packed));
     return PH_OK;
 }
 
@@ -1093,22 +1102,25 @@ ph_status ph_match_crosscheck_hamming256_frames_dev(const void *d_query, const i
         return s;
     PH_HIP(g_ctx.tmp_i.reserve((size_t)fb.t_end * sizeof(int32_t)));
     PH_HIP(g_ctx.tmp_d.reserve((size_t)fb.t_end * sizeof(int32_t)));
-    PH_HIP(g_ctx.best.reserve((size_t)fb.q_end * sizeof(unsigned long long)));
-    // Roles swapped: every train row finds its nearest query row of its own frame (so the
-    // device tables come back as tables.d_q_off = train offsets, d_t_off = query offsets).
+    PH_HIP(g_ctx.best.reserve((size_t)fb.q_end * 2 * sizeof(int32_t)));
+    int32_t *sidx = (int32_t *)g_ctx.best.p, *sdist = sidx + fb.q_end;
     FrameTables tables;
     FrameSide q = {d_query, q_offsets, fb.q_begin, fb.q_end, fb.max_nq};
     FrameSide t = {d_train, t_offsets, fb.t_begin, fb.t_end, fb.max_nt};
+    // every query row's nearest train row of its own frame ...
+    if ((s = knn_frames_locked(q, t, n_frames, fb.uniform, 1, g_ctx.part, sidx, sdist, nullptr, 0.f,
+                               st, nullptr)) != PH_OK)
+        return s;
+    // ... and, roles swapped, every train row's nearest query row (so the device tables
+    // come back as tables.d_q_off = train offsets, d_t_off = query offsets)
     if ((s = knn_frames_locked(t, q, n_frames, fb.uniform, 1, g_ctx.part2,
                                (int32_t *)g_ctx.tmp_i.p, (int32_t *)g_ctx.tmp_d.p, nullptr, 0.f,
                                st, nullptr, &tables)) != PH_OK)
         return s;
-    // (the tables' ring slot stays busy until the resolve kernels below have run:
-    // same stream, and the next call that reuses the slot waits for its event)
-    PH_HIP(crosscheck_resolve_frames_launch((const int32_t *)g_ctx.tmp_i.p,
-                                            (const int32_t *)g_ctx.tmp_d.p, tables.d_t_off,
-                                            tables.d_q_off, n_frames, fb.max_nt, fb.q_begin,
-                                            fb.q_end, (unsigned long long *)g_ctx.best.p,
+    // (the tables' ring slot stays busy until the resolve kernel below has run: same
+    // stream, and the next call that reuses the slot waits for its event)
+    PH_HIP(crosscheck_resolve_frames_launch(sidx, sdist, (const int32_t *)g_ctx.tmp_i.p,
+                                            tables.d_t_off, tables.d_q_off, n_frames, fb.max_nq,
                                             d_out_idx, d_out_dist, st));
     PH_HIP(hipEventRecord(tables.slot->done, st));
     return PH_OK;
@@ -1172,10 +1184,23 @@ ph_status ph_match_crosscheck_hamming256_shard_dev(const void *d_query, int64_t 
         return fail(PH_ERR_INVALID_ARG, "null output pointer");
     if (train_index_base < 0)
         return fail(PH_ERR_INVALID_ARG, "negative train_index_base");
-    if (nt > 0 && (int64_t)train_index_base + nt - 1 > 0x7FFFFFFF)
-        return fail(PH_ERR_TOO_LARGE, "train_index_base + nt exceeds the 32-bit index range");
+    if (nt > 0 && (int64_t)train_index_base + nt - 1 > 0x3FFFFFFF)
+        return fail(PH_ERR_TOO_LARGE, "train_index_base + nt exceeds 2^30 rows (the packed "
+                                      "candidates carry a flag below the index)");
     return crosscheck_dev_locked(d_query, nq, d_train_shard, nt, d_out_idx, d_out_dist,
-                                 pick_stream(stream), train_index_base);
+                                 pick_stream(stream), train_index_base, true);
+}
+
+ph_status ph_match_crosscheck_unpack_dev(int32_t *d_idx, int32_t *d_dist, int64_t nq, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ph_status s = ensure_ready();
+    if (s != PH_OK)
+        return s;
+    if (nq < 0 || (nq > 0 && (!d_idx || !d_dist)))
+        return fail(PH_ERR_INVALID_ARG, "bad candidate arrays");
+    PH_HIP(crosscheck_unpack_launch(d_idx, d_dist, nq, pick_stream(stream)));
+    return PH_OK;
 }
 
 ph_status ph_knn_hamming256(const uint8_t *query, int nq, size_t q_step, const uint8_t *train,

@@ -12,9 +12,11 @@ train shards  one large train set split into contiguous row ranges, one per
               gathered in rank order = ascending index order, and the merge key is
               (distance, global index), so OpenCV's lowest-index tie-break holds
               across shards.
-cross-check   the same sharding for the cross-check matcher: the swapped 1-NN pass is
-              local to the shard that owns the train row, the per-query winners are
-              all-gathered and folded the same way (match_crosscheck_train_sharded).
+cross-check   the same sharding for the cross-check matcher: every rank finds each
+              query's nearest row within its shard and whether the query is that row's
+              nearest query (the swapped search is local to the shard that owns the row);
+              the candidates are all-gathered and folded the same way, and the winner's
+              flag decides (match_crosscheck_train_sharded).
 """
 import ctypes as C
 
@@ -103,12 +105,14 @@ def match_crosscheck_train_sharded(d_query, d_train_shard, shard_base, group=Non
     """Cross-check match (BFMatcher(NORM_HAMMING, crossCheck=True).match) of all queries
     against a train set sharded over the ranks of `group`.
 
-    OpenCV's cross-check finds every TRAIN row's nearest query and then, per query, keeps
-    the best (distance, train index) among the train rows that chose it.  With the
-    queries replicated the first step is local to the shard that owns the train row; the
-    second is a per-query minimum over the shards: every rank emits its shard's winners
-    with GLOBAL train indices, the lists are all-gathered (the one exchange step) and
-    folded by (distance, global index), which keeps the lowest-index rule across shards.
+    OpenCV's cross-check keeps a pair (q, t) iff t is q's nearest train row and q is t's
+    nearest query.  With the queries replicated, a train row's nearest query is known to
+    the shard that owns the row, and a query's nearest row over the whole train set is the
+    smallest (distance, global index) among its nearest rows per shard.  So every rank
+    emits, per query, its shard's nearest row with a flag "the query is this row's nearest
+    query" packed below the GLOBAL index, the lists are all-gathered (the one exchange
+    step) and folded by (distance, index) -- the lowest-index rule holds across shards and
+    the flag rides along --, and the winner is kept where its flag is set.
 
     d_query: uint8 [nq, 32] (the same on every rank); d_train_shard: uint8 [nt_local, 32],
     rows [shard_base, shard_base + nt_local) of the global train set.  Returns (idx [nq],
@@ -131,6 +135,7 @@ def match_crosscheck_train_sharded(d_query, d_train_shard, shard_base, group=Non
     out_dst = torch.empty_like(dst)
     _lib.check(lib.ph_knn_merge_dev(all_idx.data_ptr(), all_dst.data_ptr(), all_idx.shape[0], nq,
                                     1, out_idx.data_ptr(), out_dst.data_ptr(), None, 0.0, sp))
+    _lib.check(lib.ph_match_crosscheck_unpack_dev(out_idx.data_ptr(), out_dst.data_ptr(), nq, sp))
     return out_idx.view(nq), out_dst.view(nq)
 
 

@@ -94,14 +94,19 @@ def _crosscheck_worker(rank, world, port, nq, nt, tie_stress, ret):
             t = np.concatenate([datagen.perturbed_copy(q, 9)[:nt // 2],
                                 datagen.random_descriptors(nt - nt // 2, 10)])
         lo, hi = block_bounds(nt, world, rank)
-        # the shard's winners: cross-check of all queries against the shard's rows alone
-        idx = np.full((nq, 1), -1, np.int32)
-        dst = np.full((nq, 1), 2147483647, np.int32)
-        for qi, ti, _, d in orc.match(q, t[lo:hi], cross_check=True):
-            idx[qi, 0], dst[qi, 0] = ti + lo, int(d)
+        # the shard's candidates, as ph_match_crosscheck_hamming256_shard_dev emits them: every
+        # query's nearest row within the shard (global index) with the flag "the query is
+        # that row's nearest query" packed below the index
+        si, sd = orc.knn(q, t[lo:hi], 1)
+        ti, _ = orc.knn(t[lo:hi], q, 1)
+        flag = (ti[si[:, 0], 0] == np.arange(nq)).astype(np.int32)
+        idx = (2 * (si + lo) + flag[:, None]).astype(np.int32)
+        dst = sd.astype(np.int32)
         ai, ad = allgather_candidates(torch.from_numpy(idx), torch.from_numpy(dst))
         mi, md = _merge_top2(ai.numpy(), ad.numpy(), 1)
-        got = [(qi, int(mi[qi, 0]), 0, float(md[qi, 0])) for qi in range(nq) if mi[qi, 0] >= 0]
+        # ph_match_crosscheck_unpack_dev
+        got = [(qi, int(mi[qi, 0]) >> 1, 0, float(md[qi, 0])) for qi in range(nq)
+               if mi[qi, 0] >= 0 and mi[qi, 0] & 1]
         ret[rank] = got == orc.match(q, t, cross_check=True) and len(got) > 0
     finally:
         dist.destroy_process_group()
@@ -109,8 +114,9 @@ def _crosscheck_worker(rank, world, port, nq, nt, tie_stress, ret):
 
 @pytest.mark.parametrize("tie_stress", [False, True])
 def test_crosscheck_train_sharded_world2(tie_stress):
-    """Cross-check under train sharding: per-shard winners (global indices) all-gathered and
-    folded by (distance, index) equal the unsharded cross-check match."""
+    """Cross-check under train sharding: per-shard candidates (global index + mutual flag)
+    all-gathered, folded by (distance, index) and unpacked equal the unsharded cross-check
+    match."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()

@@ -8,7 +8,7 @@ import pytest
 
 import datagen
 import oracle_bind as orc
-from test_oracle_matcher import KAT, rows
+from test_oracle_matcher import KAT, padded_rows, rows
 
 pytestmark = pytest.mark.gpu
 
@@ -69,6 +69,25 @@ def test_known_answers(posehip, case):
     assert gpu_match(posehip, q, t) == [(a, b, 0, float(d)) for a, b, d in case["match"]]
     assert gpu_match(posehip, q, t, cross_check=True) == [(a, b, 0, float(d))
                                                           for a, b, d in case["crosscheck"]]
+
+
+def test_opencv_crosscheck_regression_vector(posehip):
+    """The vector of OpenCV's own regression test for the cross-check
+    (Features2d_DMatch.issue_11855): exactly one consistent pair; host and device entry."""
+    import torch
+    reg = KAT["opencv_regression"]
+    q, t = padded_rows(reg["sources"]), padded_rows(reg["targets"])
+    want = [(a, b, 0, float(d)) for a, b, d in reg["crosscheck"]]
+    assert gpu_match(posehip, q, t, cross_check=True) == want
+    assert gpu_match(posehip, q, t) == [(a, b, 0, float(d)) for a, b, d in reg["match_without_crosscheck"]]
+    d_q, d_t = torch.from_numpy(q).to("cuda:0"), torch.from_numpy(t).to("cuda:0")
+    idx = torch.full((2,), 777, dtype=torch.int32, device="cuda:0")
+    dist = torch.full((2,), 777, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    posehip.check(posehip.load().ph_match_crosscheck_hamming256_dev(
+        d_q.data_ptr(), 2, d_t.data_ptr(), 2, idx.data_ptr(), dist.data_ptr(), None))
+    posehip.check(posehip.load().ph_stream_synchronize(None))
+    assert idx.cpu().tolist() == [-1, 0] and dist.cpu().tolist() == [INT_MAX, 0]
 
 
 SHAPES = [(1, 1), (1, 2), (2, 1), (63, 65), (64, 64), (257, 255), (500, 500), (1000, 3),
@@ -285,10 +304,11 @@ def test_shard_merge(posehip, n_shards, k):
 
 @pytest.mark.parametrize("n_shards,tie_stress", [(2, False), (3, True), (8, False), (8, True)])
 def test_crosscheck_shards(posehip, n_shards, tie_stress):
-    """Cross-check match with the train set in contiguous shards: every shard's winners
-    (ph_match_crosscheck_hamming256_shard_dev, global indices), folded by
-    ph_knn_merge_dev(k=1) as after the all-gather of a train-sharded job, equal the
-    unsharded cross-check match of the oracle."""
+    """Cross-check match with the train set in contiguous shards: every shard's candidates
+    (ph_match_crosscheck_hamming256_shard_dev: the query's nearest row within the shard,
+    global index, with the flag "the query is that row's nearest query" packed below it),
+    folded by ph_knn_merge_dev(k=1) as after the all-gather of a train-sharded job and
+    unpacked, equal the unsharded cross-check match of the oracle."""
     import torch
     from poseestimation_amd.distributed import block_bounds
     nq, nt = 1500, 2600
@@ -311,7 +331,7 @@ def test_crosscheck_shards(posehip, n_shards, tie_stress):
         ci.append(i)
         cd.append(d)
         loc = i.cpu().numpy().ravel()
-        assert ((loc == -1) | ((loc >= lo) & (loc < hi))).all()
+        assert ((loc == -1) | (((loc >> 1) >= lo) & ((loc >> 1) < hi))).all()
     all_i, all_d = torch.stack(ci).contiguous(), torch.stack(cd).contiguous()
     out_i = torch.empty((nq, 1), dtype=torch.int32, device="cuda:0")
     out_d = torch.empty((nq, 1), dtype=torch.int32, device="cuda:0")
@@ -319,8 +339,11 @@ def test_crosscheck_shards(posehip, n_shards, tie_stress):
     posehip.check(posehip.load().ph_knn_merge_dev(all_i.data_ptr(), all_d.data_ptr(), n_shards, nq,
                                                   1, out_i.data_ptr(), out_d.data_ptr(), None, 0.0,
                                                   None))
+    posehip.check(posehip.load().ph_match_crosscheck_unpack_dev(out_i.data_ptr(), out_d.data_ptr(),
+                                                                nq, None))
     posehip.check(posehip.load().ph_stream_synchronize(None))
     idx, dist = out_i.cpu().numpy().ravel(), out_d.cpu().numpy().ravel()
+    assert (dist[idx < 0] == 2147483647).all()
     got = [(int(i), int(idx[i]), 0, float(dist[i])) for i in range(nq) if idx[i] >= 0]
     want = orc.match(q, t, cross_check=True)
     assert got == want and len(got) > 0

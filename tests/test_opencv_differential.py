@@ -45,6 +45,18 @@ def test_bfmatcher_crosscheck(maker):
     assert _tuples(got) == [(a, b, d) for a, b, _, d in orc.match(q, t, cross_check=True)]
 
 
+def test_opencv_crosscheck_regression_vector_on_opencv_itself():
+    """Features2d_DMatch.issue_11855 run here on the installed OpenCV: the fixture the oracle
+    and the library are checked against must be what this OpenCV returns."""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "matcher_kat.json")))
+    reg = kat["opencv_regression"]
+    src, tgt = np.array(reg["sources"], np.uint8), np.array(reg["targets"], np.uint8)
+    got = cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(src, tgt)
+    assert _tuples(got) == [(a, b, float(d)) for a, b, d in reg["crosscheck"]]
+
+
 @pytest.mark.parametrize("n,outliers,iters,seed", [(2000, 0.3, 100, 3), (500, 0.5, 1000, 8), (64, 0.1, 100, 9)])
 def test_solvepnp_ransac_epnp(n, outliers, iters, seed):
     obj, img, R, t, _ = datagen.pnp_scene(n=n, outlier_frac=outliers, seed=seed)

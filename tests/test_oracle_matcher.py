@@ -42,6 +42,23 @@ def test_known_answers(case):
                                                  for a, b, d in case["crosscheck"]]
 
 
+def padded_rows(byte_rows):
+    """Rows given as a few bytes, zero-padded to the 32 bytes of an ORB descriptor."""
+    out = np.zeros((len(byte_rows), 32), np.uint8)
+    for i, r in enumerate(byte_rows):
+        out[i, :len(r)] = r
+    return out
+
+
+def test_opencv_crosscheck_regression_vector():
+    """The vector of OpenCV's own regression test for the cross-check
+    (Features2d_DMatch.issue_11855): one consistent pair, not two."""
+    reg = KAT["opencv_regression"]
+    q, t = padded_rows(reg["sources"]), padded_rows(reg["targets"])
+    assert orc.match(q, t, cross_check=True) == [(a, b, 0, float(d)) for a, b, d in reg["crosscheck"]]
+    assert orc.match(q, t) == [(a, b, 0, float(d)) for a, b, d in reg["match_without_crosscheck"]]
+
+
 def test_empty_inputs():
     q = rows([1, 2, 3])
     e = np.zeros((0, 32), np.uint8)
@@ -89,19 +106,23 @@ def test_tie_stress_against_numpy():
     assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
 
 
-def test_crosscheck_against_python_restatement():
-    """Independent Python statement of the four cross-check steps."""
-    q = datagen.random_descriptors(120, 7)
-    t = datagen.perturbed_copy(q, 8)[:90]
-    tq_idx, tq_dist = datagen.numpy_knn(t, q, 1)
-    dist = {}
-    nidx = {}
-    for i in range(t.shape[0]):
-        qq, d = int(tq_idx[i, 0]), int(tq_dist[i, 0])
-        if d < dist.get(qq, 2**31 - 1):
-            dist[qq], nidx[qq] = d, i
-    want = [(qq, nidx[qq], 0, float(dist[qq])) for qq in sorted(nidx)]
-    assert orc.match(q, t, cross_check=True) == want
+@pytest.mark.parametrize("tie_stress", [False, True])
+def test_crosscheck_against_python_restatement(tie_stress):
+    """Independent statement of the cross-check: the pairs (q, t) in which t is q's nearest
+    train row and q is t's nearest query (numpy brute force both ways, lowest index on ties)."""
+    if tie_stress:
+        q, t = datagen.codebook_descriptors(120, 7, words=8), datagen.codebook_descriptors(90, 8, words=8)
+    else:
+        q = datagen.random_descriptors(120, 7)
+        t = datagen.perturbed_copy(q, 8)[:90]
+    tq_idx, _ = datagen.numpy_knn(t, q, 1)
+    qt_idx, qt_dist = datagen.numpy_knn(q, t, 1)
+    want = [(qq, int(qt_idx[qq, 0]), 0, float(qt_dist[qq, 0])) for qq in range(q.shape[0])
+            if int(tq_idx[int(qt_idx[qq, 0]), 0]) == qq]
+    got = orc.match(q, t, cross_check=True)
+    assert got == want and len(got) > 0
+    # a subset of the plain matches: cross-check only removes pairs
+    assert set(got) <= set(orc.match(q, t))
 
 
 def test_multithreaded_equals_single():

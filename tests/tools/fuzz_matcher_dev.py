@@ -197,6 +197,7 @@ def case_shards():
                                None, 0.0, None))
     check(lib.ph_knn_merge_dev(axi.data_ptr(), axd.data_ptr(), S, nq, 1, x_i.data_ptr(), x_d.data_ptr(), None,
                                0.0, None))
+    check(lib.ph_match_crosscheck_unpack_dev(x_i.data_ptr(), x_d.data_ptr(), nq, None))
     check(lib.ph_stream_synchronize(None))
     ri, rd = orc.knn(q, t, k, threads=16)
     assert np.array_equal(out_i.cpu().numpy(), ri) and np.array_equal(out_d.cpu().numpy(), rd), ("shards", nq, nt, S, k, fam)
