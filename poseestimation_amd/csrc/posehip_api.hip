@@ -382,6 +382,27 @@ ph_status upload_descriptors(const uint8_t *q, int64_t nq, size_t q_step, const 
     return PH_OK;
 }
 
+// One side (query or train) of a batch of frames: device rows, HOST offset table, the
+// row range the table spans and the longest frame.
+struct FrameSide {
+    const void *d_rows;
+    const int32_t *offsets;
+    int64_t begin, end, max_rows;
+};
+
+// Device copies of a batch's tables, in the order of knn_frames_locked's (q, t) arguments,
+// and the ring slot they travel in (its `done` event is recorded behind the k-NN launch; a
+// caller that queues more kernels reading the tables records it again behind those).
+struct FrameTables {
+    const int32_t *d_q_off = nullptr, *d_t_off = nullptr;
+    Context::OffsetSlot *slot = nullptr;
+};
+
+ph_status knn_frames_locked(const FrameSide &q, const FrameSide &t, int n_frames, bool uniform,
+                            int k, DevBuf &part, int32_t *d_out_idx, int32_t *d_out_dist,
+                            uint8_t *d_keep, float ratio, hipStream_t st, hipEvent_t *ev,
+                            FrameTables *tables = nullptr);
+
 // Results of the host matcher entry points, written by the kernels straight into the
 // pinned result buffer: idx[nq*k] | dist[nq*k] | keep[nq].
 struct HostResult {
@@ -397,21 +418,48 @@ ph_status host_match_locked(const uint8_t *q, int nq, size_t q_step, const uint8
                             size_t t_step, MatchMode mode, int k, float ratio, HostResult &r)
 {
     hipStream_t st = g_ctx.stream;
-    const void *d_q = nullptr, *d_t = nullptr;
-    ph_status s = upload_descriptors(q, nq, q_step, t, nt, t_step, st, &d_q, &d_t);
-    if (s != PH_OK)
-        return s;
     const size_t n_out = (size_t)nq * k;
     const size_t dist_off = align256(n_out * 4), keep_off = dist_off + align256(n_out * 4);
     PH_HIP(g_ctx.h_out.reserve(keep_off + (size_t)nq));
     uint8_t *hb = (uint8_t *)g_ctx.h_out.p, *db = (uint8_t *)g_ctx.h_out.dp;
     int32_t *d_idx = (int32_t *)db, *d_dist = (int32_t *)(db + dist_off);
     uint8_t *d_keep = db + keep_off;
-    if (mode == MatchMode::CrossCheck)
-        s = crosscheck_dev_locked(d_q, nq, d_t, nt, d_idx, d_dist, st);
-    else
+    ph_status s;
+    if (mode == MatchMode::CrossCheck && nt > 0) {
+        // The cross-check's two searches (every query's nearest train row, every train row's
+        // nearest query) are two independent problems: a batch of two frames, ONE launch.
+        // The rows go up as q | t | q, so that the query side of the batch is the buffer
+        // from row 0 (frames q, t) and its train side the same buffer from row nq (t, q).
+        const size_t rows = (size_t)nq + nt, total = (rows + nq) * 32;
+        PH_HIP(g_ctx.h_in.reserve(total));
+        PH_HIP(g_ctx.d_in.reserve(total));
+        uint8_t *h = (uint8_t *)g_ctx.h_in.p;
+        pack_rows(h, q, nq, q_step);
+        pack_rows(h + (size_t)nq * 32, t, nt, t_step);
+        memcpy(h + rows * 32, h, (size_t)nq * 32);
+        PH_HIP(hipMemcpyAsync(g_ctx.d_in.p, h, total, hipMemcpyHostToDevice, st));
+        if ((s = scratch_guard(st)) != PH_OK)
+            return s;
+        PH_HIP(g_ctx.best.reserve(rows * 2 * sizeof(int32_t)));
+        int32_t *near_idx = (int32_t *)g_ctx.best.p, *near_dist = near_idx + rows;
+        const int32_t q_off[3] = {0, nq, (int32_t)rows}, t_off[3] = {0, nt, (int32_t)rows};
+        const int64_t longest = std::max(nq, nt);
+        FrameSide qs = {g_ctx.d_in.p, q_off, 0, (int64_t)rows, longest};
+        FrameSide ts = {(const uint8_t *)g_ctx.d_in.p + (size_t)nq * 32, t_off, 0, (int64_t)rows,
+                        longest};
+        if ((s = knn_frames_locked(qs, ts, 2, nq == nt, 1, g_ctx.part, near_idx, near_dist, nullptr,
+                                   0.f, st, nullptr)) != PH_OK)
+            return s;
+        PH_HIP(crosscheck_resolve_launch(near_idx, near_dist, near_idx + nq, nq, d_idx, d_dist, st));
+    } else if (mode == MatchMode::CrossCheck) {
+        s = crosscheck_dev_locked(nullptr, nq, nullptr, 0, d_idx, d_dist, st);
+    } else {
+        const void *d_q = nullptr, *d_t = nullptr;
+        if ((s = upload_descriptors(q, nq, q_step, t, nt, t_step, st, &d_q, &d_t)) != PH_OK)
+            return s;
         s = knn_dev_locked(d_q, nq, d_t, nt, k, 0, d_idx, d_dist,
                            mode == MatchMode::Ratio ? d_keep : nullptr, ratio, g_ctx.part, st);
+    }
     if (s != PH_OK)
         return s;
     PH_HIP(hipStreamSynchronize(st));
@@ -508,6 +556,52 @@ ph_status upload_frame_tables(const int32_t *q_offsets, const int32_t *t_offsets
     fb.d_t_off = fb.d_q_off + (n_frames + 1);
     g_ctx.off_cached = slot_index;
     g_ctx.off_cached_frames = n_frames;
+    return PH_OK;
+}
+
+// k-NN of every frame's q rows among its t rows, into outputs indexed by q row; the
+// caller holds g_mu.  Picks the matrix-core or the popcount kernel by size.
+ph_status knn_frames_locked(const FrameSide &q, const FrameSide &t, int n_frames, bool uniform,
+                            int k, DevBuf &part, int32_t *d_out_idx, int32_t *d_out_dist,
+                            uint8_t *d_keep, float ratio, hipStream_t st, hipEvent_t *ev,
+                            FrameTables *tables)
+{
+    ph_status s;
+    FrameBatch fb; // carries the device tables out of upload_frame_tables
+    Context::OffsetSlot *slot = nullptr;
+    const bool mfma = g_ctx.knn_path == 2 ||
+                      (g_ctx.knn_path == 0 && knn_mfma_pays_frames(n_frames, q.max_rows, t.max_rows));
+    MfmaPlan mp;
+    KnnPlan plan;
+    if (mfma) {
+        mp = knn_mfma_plan_frames(n_frames, q.max_rows, t.max_rows, q.end, g_ctx.n_cus);
+    } else {
+        plan = knn_plan_frames(n_frames, q.max_rows, t.max_rows, q.end, g_ctx.n_cus);
+        if (frame_rows_per_split(t.max_rows, plan) * (int64_t)plan.n_splits < t.max_rows)
+            return fail(PH_ERR_TOO_LARGE, "set of %lld rows is too large for one call",
+                        (long long)t.max_rows);
+    }
+    if ((s = scratch_guard(st)) != PH_OK)
+        return s;
+    PH_HIP(part.reserve(mfma ? mp.part_bytes : plan.part_bytes));
+    if (mfma) {
+        PH_HIP(g_ctx.xt.reserve(knn_mfma_expanded_bytes(t.end - t.begin)));
+    }
+    if ((s = upload_frame_tables(q.offsets, t.offsets, n_frames, st, fb, slot)) != PH_OK)
+        return s;
+    if (mfma)
+        PH_HIP(knn_mfma_frames_launch(mp, q.d_rows, fb.d_q_off, q.end, t.d_rows,
+                                      fb.d_t_off, t.begin, t.end, n_frames, k, g_ctx.xt.p,
+                                      (uint32_t *)part.p, d_out_idx, d_out_dist, d_keep, ratio,
+                                      st, ev, uniform));
+    else
+        PH_HIP(knn_frames_launch(plan, q.d_rows, fb.d_q_off, t.d_rows, fb.d_t_off, n_frames, q.end,
+                                 k, (uint32_t *)part.p, d_out_idx, d_out_dist, d_keep, ratio, st,
+                                 ev, uniform));
+    PH_HIP(hipEventRecord(slot->done, st));
+    g_ctx.last_path = mfma ? 1 : 0;
+    if (tables)
+        *tables = FrameTables{fb.d_q_off, fb.d_t_off, slot};
     return PH_OK;
 }
 
@@ -965,68 +1059,6 @@ ph_status ph_knn_hamming256_noalloc_dev(const void *d_query, int64_t nq, const v
     PH_HIP(knn_launch(plan, d_query, nq, d_train, nt, k, train_index_base, (uint32_t *)ws,
                       d_out_idx, d_out_dist, d_keep, ratio, st, nullptr));
     g_ctx.last_path = 0;
-    return PH_OK;
-}
-
-// One side (query or train) of a batch of frames: device rows, HOST offset table, the
-// row range the table spans and the longest frame.
-struct FrameSide {
-    const void *d_rows;
-    const int32_t *offsets;
-    int64_t begin, end, max_rows;
-};
-
-// Device copies of a batch's tables, in the order of knn_frames_locked's (q, t) arguments,
-// and the ring slot they travel in (its `done` event is recorded behind the k-NN launch; a
-// caller that queues more kernels reading the tables records it again behind those).
-struct FrameTables {
-    const int32_t *d_q_off = nullptr, *d_t_off = nullptr;
-    Context::OffsetSlot *slot = nullptr;
-};
-
-// k-NN of every frame's q rows among its t rows, into outputs indexed by q row; the
-// caller holds g_mu.  Picks the matrix-core or the popcount kernel by size.
-ph_status knn_frames_locked(const FrameSide &q, const FrameSide &t, int n_frames, bool uniform,
-                            int k, DevBuf &part, int32_t *d_out_idx, int32_t *d_out_dist,
-                            uint8_t *d_keep, float ratio, hipStream_t st, hipEvent_t *ev,
-                            FrameTables *tables = nullptr)
-{
-    ph_status s;
-    FrameBatch fb; // carries the device tables out of upload_frame_tables
-    Context::OffsetSlot *slot = nullptr;
-    const bool mfma = g_ctx.knn_path == 2 ||
-                      (g_ctx.knn_path == 0 && knn_mfma_pays_frames(n_frames, q.max_rows, t.max_rows));
-    MfmaPlan mp;
-    KnnPlan plan;
-    if (mfma) {
-        mp = knn_mfma_plan_frames(n_frames, q.max_rows, t.max_rows, q.end, g_ctx.n_cus);
-    } else {
-        plan = knn_plan_frames(n_frames, q.max_rows, t.max_rows, q.end, g_ctx.n_cus);
-        if (frame_rows_per_split(t.max_rows, plan) * (int64_t)plan.n_splits < t.max_rows)
-            return fail(PH_ERR_TOO_LARGE, "set of %lld rows is too large for one call",
-                        (long long)t.max_rows);
-    }
-    if ((s = scratch_guard(st)) != PH_OK)
-        return s;
-    PH_HIP(part.reserve(mfma ? mp.part_bytes : plan.part_bytes));
-    if (mfma) {
-        PH_HIP(g_ctx.xt.reserve(knn_mfma_expanded_bytes(t.end - t.begin)));
-    }
-    if ((s = upload_frame_tables(q.offsets, t.offsets, n_frames, st, fb, slot)) != PH_OK)
-        return s;
-    if (mfma)
-        PH_HIP(knn_mfma_frames_launch(mp, q.d_rows, fb.d_q_off, q.end, t.d_rows,
-                                      fb.d_t_off, t.begin, t.end, n_frames, k, g_ctx.xt.p,
-                                      (uint32_t *)part.p, d_out_idx, d_out_dist, d_keep, ratio,
-                                      st, ev, uniform));
-    else
-        PH_HIP(knn_frames_launch(plan, q.d_rows, fb.d_q_off, t.d_rows, fb.d_t_off, n_frames, q.end,
-                                 k, (uint32_t *)part.p, d_out_idx, d_out_dist, d_keep, ratio, st,
-                                 ev, uniform));
-    PH_HIP(hipEventRecord(slot->done, st));
-    g_ctx.last_path = mfma ? 1 : 0;
-    if (tables)
-        *tables = FrameTables{fb.d_q_off, fb.d_t_off, slot};
     return PH_OK;
 }
 
