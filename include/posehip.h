@@ -85,7 +85,7 @@ ph_status ph_match_hamming256(const uint8_t *query, int nq, size_t q_step, const
 /* match(query, train) of a matcher built with crossCheck=true:
  * src/orb_feature_matching/matcher.py:18,21.  A pair (q, t) is returned iff t is q's
  * nearest train row AND q is t's nearest query row, each with the lowest-index rule on
- * ties (cv::batchDistance's crosscheck branch since OpenCV 3.4.2 / 4.0, pinned by its
+ * ties (cv::batchDistance's crosscheck branch since the fix of OpenCV issue 11855 in 2018, pinned by its
  * regression test Features2d_DMatch.issue_11855).  out holds up to nq entries in
  * ascending queryIdx; queries without a consistent pair are dropped. */
 ph_status ph_match_crosscheck_hamming256(const uint8_t *query, int nq, size_t q_step,

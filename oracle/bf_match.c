@@ -183,7 +183,7 @@ int orc_match(const uint8_t *q, int nq, size_t q_step, const uint8_t *t, int nt,
  *   4. for train i ascending: q=tidx[i]; if (tdist[i] < dist[q] && sidx[q] == i) take it;
  *   5. emit (q, nidx[q], dist[q]) for queries with nidx[q]>=0, ascending q.
  * A pair survives iff each row is the other's nearest neighbour ("the BFMatcher will only
- * return consistent pairs").  OpenCV before 3.4.2 / 4.0 lacked step 3 and its condition
+ * return consistent pairs").  OpenCV before the fix of its issue 11855 (2018; every 4.x release has it) lacked step 3 and its condition
  * (a query was paired with the closest train row among those whose nearest query it was,
  * which is not mutual); the library's regression test Features2d_DMatch.issue_11855
  * (modules/features2d/test/test_matchers_algorithmic.cpp) pins the mutual form, and its
