@@ -425,9 +425,15 @@ ph_status host_match_locked(const uint8_t *q, int nq, size_t q_step, const uint8
     int32_t *d_idx = (int32_t *)db, *d_dist = (int32_t *)(db + dist_off);
     uint8_t *d_keep = db + keep_off;
     ph_status s;
-    if (mode == MatchMode::CrossCheck && nt > 0) {
-        // The cross-check's two searches (every query's nearest train row, every train row's
-        // nearest query) are two independent problems: a batch of two frames, ONE launch.
+    // The cross-check's two searches (every query's nearest train row, every train row's
+    // nearest query) are two independent problems; when the two sets are of similar, moderate
+    // size (a frame against a frame, the reference's case) they go down as a batch of two
+    // frames in ONE launch.  A batch is planned for its longest frame on either side, so very
+    // unequal or very large sets keep the two separate searches.
+    const int64_t longer = std::max(nq, nt), shorter = std::min(nq, nt);
+    const bool as_two_frames = mode == MatchMode::CrossCheck && nt > 0 && longer <= 65536 &&
+                               longer <= 8 * shorter;
+    if (as_two_frames) {
         // The rows go up as q | t | q, so that the query side of the batch is the buffer
         // from row 0 (frames q, t) and its train side the same buffer from row nq (t, q).
         const size_t rows = (size_t)nq + nt, total = (rows + nq) * 32;
@@ -443,22 +449,22 @@ ph_status host_match_locked(const uint8_t *q, int nq, size_t q_step, const uint8
         PH_HIP(g_ctx.best.reserve(rows * 2 * sizeof(int32_t)));
         int32_t *near_idx = (int32_t *)g_ctx.best.p, *near_dist = near_idx + rows;
         const int32_t q_off[3] = {0, nq, (int32_t)rows}, t_off[3] = {0, nt, (int32_t)rows};
-        const int64_t longest = std::max(nq, nt);
-        FrameSide qs = {g_ctx.d_in.p, q_off, 0, (int64_t)rows, longest};
+        FrameSide qs = {g_ctx.d_in.p, q_off, 0, (int64_t)rows, longer};
         FrameSide ts = {(const uint8_t *)g_ctx.d_in.p + (size_t)nq * 32, t_off, 0, (int64_t)rows,
-                        longest};
+                        longer};
         if ((s = knn_frames_locked(qs, ts, 2, nq == nt, 1, g_ctx.part, near_idx, near_dist, nullptr,
                                    0.f, st, nullptr)) != PH_OK)
             return s;
         PH_HIP(crosscheck_resolve_launch(near_idx, near_dist, near_idx + nq, nq, d_idx, d_dist, st));
-    } else if (mode == MatchMode::CrossCheck) {
-        s = crosscheck_dev_locked(nullptr, nq, nullptr, 0, d_idx, d_dist, st);
     } else {
         const void *d_q = nullptr, *d_t = nullptr;
         if ((s = upload_descriptors(q, nq, q_step, t, nt, t_step, st, &d_q, &d_t)) != PH_OK)
             return s;
-        s = knn_dev_locked(d_q, nq, d_t, nt, k, 0, d_idx, d_dist,
-                           mode == MatchMode::Ratio ? d_keep : nullptr, ratio, g_ctx.part, st);
+        if (mode == MatchMode::CrossCheck)
+            s = crosscheck_dev_locked(d_q, nq, d_t, nt, d_idx, d_dist, st);
+        else
+            s = knn_dev_locked(d_q, nq, d_t, nt, k, 0, d_idx, d_dist,
+                               mode == MatchMode::Ratio ? d_keep : nullptr, ratio, g_ctx.part, st);
     }
     if (s != PH_OK)
         return s;
