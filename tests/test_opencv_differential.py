@@ -45,6 +45,23 @@ def test_bfmatcher_crosscheck(maker):
     assert _tuples(got) == [(a, b, d) for a, b, _, d in orc.match(q, t, cross_check=True)]
 
 
+def test_known_answer_file_on_opencv_itself():
+    """Every hand-computed case of tests/golden/matcher_kat.json on the installed OpenCV: plain
+    match, k = 2 and cross-check (this is what decides the cross-check's tie rule, the one
+    detail of that file written down with less than full confidence)."""
+    from test_oracle_matcher import KAT, rows
+    for case in KAT["cases"]:
+        q, t = rows(case["query"]), rows(case["train"])
+        assert _tuples(cv2.BFMatcher(cv2.NORM_HAMMING).match(q, t)) == \
+            [(a, b, float(d)) for a, b, d in case["match"]], case["name"]
+        assert _tuples(cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(q, t)) == \
+            [(a, b, float(d)) for a, b, d in case["crosscheck"]], case["name"]
+        got = cv2.BFMatcher(cv2.NORM_HAMMING).knnMatch(q, t, k=2)
+        want = [[(i, d) for i, d in zip(ri, rd) if i >= 0]
+                for ri, rd in zip(case["knn2_idx"], case["knn2_dist"])]
+        assert [[(m.trainIdx, int(m.distance)) for m in r] for r in got] == want, case["name"]
+
+
 def test_opencv_crosscheck_regression_vector_on_opencv_itself():
     """Features2d_DMatch.issue_11855 run here on the installed OpenCV: the fixture the oracle
     and the library are checked against must be what this OpenCV returns."""
