@@ -17,9 +17,10 @@ run also times the train-sharded form of the matcher (BASELINE configs[4] scaled
 rank count: queries replicated, train rows in contiguous shards, one all-gather of the
 per-shard candidates, merge) and reports it as `train_sharded`.
 
-The timed region is never shorter than --min-seconds: if the requested steps finish
-sooner they are raised (the same number on every rank) and the region is timed again;
-`steps` is the number actually timed, `steps_requested` what the command line asked for.
+`value` comes from EXACTLY --steps timed steps after the warm-up (at least --warmup steps
+and 50 ms, past the clock ramp).  When those steps are less than --min-seconds of work, a
+second, longer region (the same count on every rank) is timed as well and reported as
+`sustained`.
 
 Prints one JSON line on rank 0.
 """
@@ -70,12 +71,33 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpu_count():
+    """GPUs this process could open, counted WITHOUT the HIP runtime (the parent of the ranks
+    must stay GPU-free): compute nodes with SIMDs in the KFD topology, capped by the
+    *_VISIBLE_DEVICES lists."""
+    import glob
+    n = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(prop) as f:
+                for line in f:
+                    if line.startswith("simd_count ") and int(line.split()[1]) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def launch_ranks(args):
     """`bench.py --gpus N` started bare: start the N ranks as children (one process per GPU,
     torch.distributed.run on 127.0.0.1) from this process, which has made no GPU call and
-    makes none, and pass their output and exit code on."""
-    import torch
-    have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    makes none (it neither imports torch nor loads the HIP runtime), and pass their output
+    and exit code on."""
+    have = visible_gpu_count()
     if args.dist_backend == "nccl" and have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s)", file=sys.stderr)
         return 2
@@ -97,10 +119,12 @@ def all_reduce_max(value, torch, dist, dev, backend):
 
 def timed_region(step, steps, warmup, min_seconds, min_warmup_seconds, torch, dist, dev, world,
                  backend):
-    """Warm up (at least `warmup` steps and `min_warmup_seconds`), then time `steps` steps
-    between barrier + synchronize on both sides, MAX over ranks.  A region shorter than
-    `min_seconds` is timed again with proportionally more steps (every rank derives the same
-    count from the all-reduced time).  Returns (seconds, steps timed)."""
+    """Warm up (at least `warmup` steps and `min_warmup_seconds`), then time EXACTLY `steps`
+    steps between barrier + synchronize on both sides, MAX over ranks: that region is the
+    headline.  When it is shorter than `min_seconds`, a second, longer region of
+    proportionally more steps (every rank derives the same count from the all-reduced time)
+    is timed as well and reported beside it as the sustained rate.
+    Returns (seconds, steps) of the exact region and (seconds, steps) of the longest one."""
     def barrier():
         if world > 1:
             dist.barrier()
@@ -124,13 +148,14 @@ def timed_region(step, steps, warmup, min_seconds, min_warmup_seconds, torch, di
         done += 1
         if done % 16 == 0:
             torch.cuda.synchronize()   # bound the queue while the clock is being read
-    el = run(steps)
+    exact = (run(steps), steps)
+    el, n = exact
     for _ in range(3):
         if el >= min_seconds:
             break
-        steps = int(math.ceil(steps * min_seconds * 1.15 / max(el, 1e-6)))
-        el = run(steps)
-    return el, steps
+        n = int(math.ceil(n * min_seconds * 1.15 / max(el, 1e-6)))
+        el = run(n)
+    return exact, (el, n)
 
 
 def ransac_roofline(args, torch, lib, _lib, step, problems, hyps, n_points):
@@ -156,7 +181,8 @@ def ransac_roofline(args, torch, lib, _lib, step, problems, hyps, n_points):
     score_flop = counts["score_fp64_per_hyp"]["flop"] / counts["n_points"] * n_points \
         + 5.0 * n_points
     total = problems * hyps
-    round_hyps = min(total, 256 * 128)          # one GPU-full of solves per launch
+    n_cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    round_hyps = min(total, n_cus * 128)        # one GPU-full of solves per launch
     n_rounds = math.ceil(total / round_hyps)
     last_hyps = total - (n_rounds - 1) * round_hyps
     # the solve launch timed with nothing else on the GPU (the first round of a call; the
@@ -171,7 +197,7 @@ def ransac_roofline(args, torch, lib, _lib, step, problems, hyps, n_points):
     traffic = None   # HBM bytes per solve launch from the PMC passes of the same shape
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_ransac_16x4096x2000.json")))
-        if (hyps, n_points) == (4096, 2000) and problems * hyps >= 256 * 128:  # full rounds
+        if (hyps, n_points) == (4096, 2000) and problems * hyps >= n_cus * 128 == 256 * 128:  # full rounds
             traffic = pmc["derived"]["void posehip::ransac_solve_kernel<32>"]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -197,9 +223,13 @@ def ransac_roofline(args, torch, lib, _lib, step, problems, hyps, n_points):
         "score_kernel": {
             "kernel": "ransac_score_kernel", "kernel_ms": score_ms,
             "hypotheses": last_hyps,
-            "flop_per_hypothesis": score_flop,
-            "achieved_TFLOPs": last_hyps * score_flop / (score_ms * 1e-3) / 1e12,
-            "frac_of_fp64_peak": last_hyps * score_flop / (score_ms * 1e-3) / peak,
+            "flop_per_hypothesis_nominal": score_flop,
+            "nominal_TFLOPs": last_hyps * score_flop / (score_ms * 1e-3) / 1e12,
+            "nominal_frac_of_fp64_peak": last_hyps * score_flop / (score_ms * 1e-3) / peak,
+            "nominal_note": "operations of the exact (sequential-statement) evaluation per "
+                            "verdict; the kernel settles most verdicts in packed fp32 with a "
+                            "rigorous error bound and runs the exact form only where that cannot "
+                            "decide, so this is work delivered, not instructions executed",
             "bytes_per_hypothesis": 20 * n_points,
             "what": f"{n_points} reprojections per hypothesis: 25 fp64 + 5 fp32 operations and "
                     f"20 bytes of correspondence each"},
@@ -249,7 +279,7 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
     torch.cuda.synchronize()
     single_ms = (time.perf_counter() - t0) / 5 * 1e3
 
-    el, r_steps = timed_region(step, args.ransac_steps, 2, args.min_seconds / 2,
+    _, (el, r_steps) = timed_region(step, args.ransac_steps, 2, args.min_seconds / 2,
                                args.min_warmup_seconds, torch, dist, dev, world, args.dist_backend)
     res = {
         "value": float(H) * P * world * r_steps / el,
@@ -335,45 +365,20 @@ def bench_train_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr):
         g.manual_seed(seed)
         return torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
 
+    from poseestimation_amd.distributed import knn_train_sharded
     d_q = rows(nq, 4999)
     d_t = rows(ntl, 5000 + rank)
     base = rank * ntl
-    cand = torch.empty((2, nq, 2), dtype=torch.int32, device=dev)       # idx | dist of this shard
-    gathered = torch.empty((world * 2, nq, 2), dtype=torch.int32, device=dev)
-    out_i = torch.empty((nq, 2), dtype=torch.int32, device=dev)
-    out_d = torch.empty((nq, 2), dtype=torch.int32, device=dev)
-    keep = torch.empty(nq, dtype=torch.uint8, device=dev)
-    ratio = C.c_float(args.ratio)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    last = {}
 
     def step(timed=False):
-        if timed:
-            ev[0].record()
-        _lib.check(lib.ph_knn_hamming256_dev(d_q.data_ptr(), nq, d_t.data_ptr(), ntl, 2, base,
-                                             cand[0].data_ptr(), cand[1].data_ptr(), None,
-                                             C.c_float(0.0), sptr))
-        if timed:
-            ev[1].record()
-        if world > 1:
-            if args.dist_backend == "nccl":
-                dist.all_gather_into_tensor(gathered, cand)
-            else:   # gloo rehearsal: the exchange goes through host tensors
-                host = torch.empty(gathered.shape, dtype=torch.int32)
-                dist.all_gather_into_tensor(host, cand.cpu())
-                gathered.copy_(host)
-            src = gathered.view(world, 2, nq, 2)
-            all_i, all_d = src[:, 0].contiguous(), src[:, 1].contiguous()
-        else:
-            all_i, all_d = cand[0:1], cand[1:2]
-        if timed:
-            ev[2].record()
-        _lib.check(lib.ph_knn_merge_dev(all_i.data_ptr(), all_d.data_ptr(), world, nq, 2,
-                                        out_i.data_ptr(), out_d.data_ptr(), keep.data_ptr(), ratio,
-                                        sptr))
-        if timed:
-            ev[3].record()
+        # the product's own sequence: per-shard search with global indices, all-gather of
+        # the candidates in rank order (host-staged under gloo), merge + ratio test
+        last["out"] = knn_train_sharded(d_q, d_t, base, 2, ratio=args.ratio,
+                                        events=ev if timed else None)
 
-    el, steps = timed_region(step, args.shard_steps, 1, 0.0, 0.0, torch, dist, dev, world,
+    _, (el, steps) = timed_region(step, args.shard_steps, 1, 0.0, 0.0, torch, dist, dev, world,
                              args.dist_backend)
     step(timed=True)
     torch.cuda.synchronize()
@@ -388,10 +393,12 @@ def bench_train_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr):
                                   f"rank + merge" if world > 1 else "one shard (no exchange)"},
         "search_ms": ev[0].elapsed_time(ev[1]),
         "allgather_ms": ev[1].elapsed_time(ev[2]) if world > 1 else None,
-        "allgather_bytes_sent_per_rank": cand.numel() * 4 if world > 1 else 0,
-        "allgather_bytes_received_per_rank": cand.numel() * 4 * (world - 1),
+        "allgather_bytes_sent_per_rank": 2 * nq * 2 * 4 if world > 1 else 0,
+        "allgather_bytes_received_per_rank": 2 * nq * 2 * 4 * (world - 1),
         "merge_ms": ev[2].elapsed_time(ev[3]),
     }
+    out_i, out_d, keep = last["out"]
+    ratio = C.c_float(args.ratio)
     if rank == 0:
         # spot check: sampled queries against the whole train set in one unsharded call
         pick = torch.randperm(nq, device=dev, generator=torch.Generator(device=dev).manual_seed(1))[:256]
@@ -428,6 +435,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     # one rank per GPU; under --dist-backend gloo several ranks may share a GPU (rehearsal)
     dev_index = local_rank if args.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
+    if args.dist_backend == "nccl" and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but this node shows "
+                         f"{torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -485,7 +495,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    elapsed, steps_run = timed_region(step, args.steps, args.warmup, args.min_seconds,
+    (elapsed, steps_run), (long_s, long_steps) = timed_region(step, args.steps, args.warmup, args.min_seconds,
                                       args.min_warmup_seconds, torch, dist, dev, world,
                                       args.dist_backend)
 
@@ -678,10 +688,14 @@ def main():
             "unit": "Hamming evals/s",
             "n_gpus": world,
             "steps": steps_run,
-            "steps_requested": args.steps,
             "warmup": args.warmup,
             "timed_region_s": elapsed,
             "ms_per_step": elapsed / steps_run * 1e3,
+            "sustained": {"value": evals_per_step_all * long_steps / long_s, "steps": long_steps,
+                          "timed_region_s": long_s, "ms_per_step": long_s / long_steps * 1e3,
+                          "what": f"the same step timed the same way over at least "
+                                  f"{args.min_seconds} s (the {steps_run} steps asked for are "
+                                  f"{elapsed * 1e3:.1f} ms of work)"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

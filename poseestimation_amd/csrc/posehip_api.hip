@@ -606,6 +606,7 @@ ph_status knn_frames_locked(const FrameSide &q, const FrameSide &t, int n_frames
                                  ev, uniform));
     PH_HIP(hipEventRecord(slot->done, st));
     g_ctx.last_path = mfma ? 1 : 0;
+    g_ctx.ev_valid = ev != nullptr; // the events, if any, belong to this call's kernels
     if (tables)
         *tables = FrameTables{fb.d_q_off, fb.d_t_off, slot};
     return PH_OK;
@@ -822,6 +823,7 @@ void ph_shutdown(void)
         if (e)
             (void)hipEventDestroy(e);
     g_ctx = Context();
+    ransac_set_solve_variant(0); // a measurement setting, like the k-NN path: does not outlive the binding
 }
 
 const char *ph_last_error_string(void) { return g_err; }
@@ -1050,6 +1052,7 @@ ph_status ph_knn_hamming256_noalloc_dev(const void *d_query, int64_t nq, const v
                                (uint32_t *)(ws + image), d_out_idx, d_out_dist, d_keep, ratio, st,
                                nullptr));
         g_ctx.last_path = 1;
+        g_ctx.ev_valid = false; // no events recorded: an earlier call's must not be read as this one's
         return PH_OK;
     }
     const KnnPlan plan = knn_plan(nq, nt, g_ctx.n_cus);
@@ -1065,6 +1068,7 @@ ph_status ph_knn_hamming256_noalloc_dev(const void *d_query, int64_t nq, const v
     PH_HIP(knn_launch(plan, d_query, nq, d_train, nt, k, train_index_base, (uint32_t *)ws,
                       d_out_idx, d_out_dist, d_keep, ratio, st, nullptr));
     g_ctx.last_path = 0;
+    g_ctx.ev_valid = false;
     return PH_OK;
 }
 
@@ -1106,7 +1110,6 @@ ph_status ph_knn_hamming256_frames_dev(const void *d_query, const int32_t *q_off
     if ((s = knn_frames_locked(q, t, n_frames, fb.uniform, k, g_ctx.part, d_out_idx, d_out_dist,
                                d_keep, ratio, st, ev)) != PH_OK)
         return s;
-    g_ctx.ev_valid = ev != nullptr;
     return PH_OK;
 }
 
@@ -1550,6 +1553,8 @@ ph_status ph_ransac_epnp_hypotheses_batched_dev(const float *d_obj, const float 
     if (!d_point_offsets || !d_subsets || !d_models || !d_counts)
         return fail(PH_ERR_INVALID_ARG, "null pointer");
     const double thr = reproj_err;
+    // (n_problems * hyp_per_problem > 0 here: an empty batch has returned above, so the
+    // launch below records every event it is given)
     hipEvent_t *ev = g_ctx.profiling ? g_ctx.pnp_ev : nullptr;
     double *front = nullptr;
     if ((s = pnp_front_workspace((int64_t)n_problems * hyp_per_problem, pick_stream(stream),

@@ -45,8 +45,11 @@ def allgather_candidates(cand_idx, cand_dist, group=None):
     """All-gather of per-shard k-best lists.
 
     cand_idx, cand_dist: int32 [nq, k] on this rank (global train indices).
-    Returns ([world, nq, k] idx, [world, nq, k] dist), shards in rank order.
-    Works with any backend (RCCL on GPUs, gloo on CPU tensors).
+    Returns ([world, nq, k] idx, [world, nq, k] dist), shards in rank order, on the
+    device of the inputs.  Under RCCL ("nccl") GPU tensors are exchanged in place, in the
+    order of torch's current stream.  Any other backend (gloo: ranks that share a GPU, or
+    CPU tensors) gets host tensors: GPU candidates are staged through the host, the copy
+    out being ordered behind the kernels on torch's current stream.
     """
     world = dist.get_world_size(group)
     if cand_idx.dtype != torch.int32 or cand_dist.dtype != torch.int32:
@@ -56,10 +59,24 @@ def allgather_candidates(cand_idx, cand_dist, group=None):
     # one message per rank: idx and dist travel together ([2, nq, k])
     mine = torch.stack([cand_idx, cand_dist]).contiguous()
     nq, k = cand_idx.shape
+    dev = mine.device
+    staged = dev.type != "cpu" and dist.get_backend(group) != "nccl"
+    if staged:
+        mine = mine.cpu()  # waits for the current stream's work on `mine`
     gathered = torch.empty((world * 2, nq, k), dtype=torch.int32, device=mine.device)
     dist.all_gather_into_tensor(gathered, mine, group=group)  # concatenates along dim 0
+    if staged:
+        gathered = gathered.to(dev)
     gathered = gathered.view(world, 2, nq, k)
     return gathered[:, 0].contiguous(), gathered[:, 1].contiguous()
+
+
+def _gather_shards(idx, dst, group):
+    """The exchange step of a train-sharded search.  A process that has no process group
+    is a job of one rank: its shard is the whole train set and nothing is exchanged."""
+    if dist.is_available() and dist.is_initialized():
+        return allgather_candidates(idx, dst, group)
+    return idx.unsqueeze(0), dst.unsqueeze(0)
 
 
 def _stream_ptr():
@@ -67,13 +84,16 @@ def _stream_ptr():
     return C.c_void_p(s) if s else None
 
 
-def knn_train_sharded(d_query, d_train_shard, shard_base, k, ratio=None, group=None):
+def knn_train_sharded(d_query, d_train_shard, shard_base, k, ratio=None, group=None,
+                      events=None):
     """k-NN of all queries against a train set sharded over the ranks of `group`.
 
     d_query: uint8 [nq, 32] on this rank's GPU (the same queries on every rank);
     d_train_shard: uint8 [nt_local, 32], rows [shard_base, shard_base + nt_local)
     of the global train set.  Returns (idx [nq, k], dist [nq, k], keep [nq] or
-    None) as GPU tensors, identical on every rank.
+    None) as GPU tensors, identical on every rank.  events: optionally four
+    torch.cuda.Event objects, recorded on the current stream before the search, behind
+    it, behind the all-gather and behind the merge (a benchmark's phase clock).
     """
     lib = _lib.load()
     nq, nt = d_query.shape[0], d_train_shard.shape[0]
@@ -86,10 +106,17 @@ def knn_train_sharded(d_query, d_train_shard, shard_base, k, ratio=None, group=N
     if sp is None:
         raise RuntimeError("run under `with torch.cuda.stream(torch.cuda.Stream())`: torch's "
                            "default stream has no handle to pass through the C ABI")
-    _lib.check(lib.ph_knn_hamming256_dev(d_query.data_ptr(), nq, d_train_shard.data_ptr(), nt, k,
+    if events:
+        events[0].record()
+    _lib.check(lib.ph_knn_hamming256_dev(d_query.data_ptr(), nq,
+                                         d_train_shard.data_ptr() if nt else None, nt, k,
                                          int(shard_base), idx.data_ptr(), dst.data_ptr(), None,
                                          0.0, sp))
-    all_idx, all_dst = allgather_candidates(idx, dst, group)
+    if events:
+        events[1].record()
+    all_idx, all_dst = _gather_shards(idx, dst, group)
+    if events:
+        events[2].record()
     world = all_idx.shape[0]
     out_idx = torch.empty_like(idx)
     out_dst = torch.empty_like(dst)
@@ -98,6 +125,8 @@ def knn_train_sharded(d_query, d_train_shard, shard_base, k, ratio=None, group=N
                                     out_idx.data_ptr(), out_dst.data_ptr(),
                                     keep.data_ptr() if keep is not None else None,
                                     float(ratio) if ratio is not None else 0.0, sp))
+    if events:
+        events[3].record()
     return out_idx, out_dst, keep
 
 
@@ -130,13 +159,41 @@ def match_crosscheck_train_sharded(d_query, d_train_shard, shard_base, group=Non
     _lib.check(lib.ph_match_crosscheck_hamming256_shard_dev(
         d_query.data_ptr(), nq, d_train_shard.data_ptr() if nt else None, nt, int(shard_base),
         idx.data_ptr(), dst.data_ptr(), sp))
-    all_idx, all_dst = allgather_candidates(idx, dst, group)
+    all_idx, all_dst = _gather_shards(idx, dst, group)
     out_idx = torch.empty_like(idx)
     out_dst = torch.empty_like(dst)
     _lib.check(lib.ph_knn_merge_dev(all_idx.data_ptr(), all_dst.data_ptr(), all_idx.shape[0], nq,
                                     1, out_idx.data_ptr(), out_dst.data_ptr(), None, 0.0, sp))
     _lib.check(lib.ph_match_crosscheck_unpack_dev(out_idx.data_ptr(), out_dst.data_ptr(), nq, sp))
     return out_idx.view(nq), out_dst.view(nq)
+
+
+def knn_frame_block_resident(db, d_query, k, ratio=None):
+    """This rank's block of a frame-sharded job against a train set resident in HBM (a
+    model database uploaded once with ph_db_upload, replicated on every rank): the frames
+    of the block are independent, all match the same database, and their query rows lie
+    one after the other in d_query, so the whole block is ONE search and nothing is
+    exchanged between ranks.
+
+    db: handle from ph_db_upload (int or ctypes.c_void_p); d_query: uint8 [rows, 32] GPU
+    tensor, the rows of frames_of_rank(...) concatenated.  Returns (idx [rows, k],
+    dist [rows, k], keep [rows] or None); row r belongs to frame r // rows_per_frame of
+    the block, train indices are those of the database.
+    """
+    lib = _lib.load()
+    sp = _stream_ptr()
+    if sp is None:
+        raise RuntimeError("run under `with torch.cuda.stream(torch.cuda.Stream())`: torch's "
+                           "default stream has no handle to pass through the C ABI")
+    rows, dev = d_query.shape[0], d_query.device
+    idx = torch.empty((rows, k), dtype=torch.int32, device=dev)
+    dst = torch.empty((rows, k), dtype=torch.int32, device=dev)
+    keep = torch.empty(rows, dtype=torch.uint8, device=dev) if ratio is not None else None
+    _lib.check(lib.ph_db_knn_hamming256_dev(
+        db, d_query.data_ptr() if rows else None, rows, k, idx.data_ptr(), dst.data_ptr(),
+        keep.data_ptr() if keep is not None else None,
+        float(ratio) if ratio is not None else 0.0, sp))
+    return idx, dst, keep
 
 
 def knn_frames(d_query, q_offsets, d_train, t_offsets, k, ratio=None):

@@ -861,3 +861,55 @@ def test_resident_database_device_queries(posehip):
     posehip.check(lib.ph_stream_synchronize(None))
     assert idx[0].tolist() == [-1, -1] and dist[0].tolist() == [INT_MAX, INT_MAX]
     posehip.check(lib.ph_db_free(empty))
+
+
+@all_paths
+def test_batched_frames_config_per_gpu_blocks(posehip):
+    """BASELINE configs[3] as the frame-sharded job deals it: 4096 frames x 2000 descriptors
+    against a 50k-row model database, 8 ranks, 512 frames per rank.  Each rank's block is ONE
+    ph_db_knn_hamming256_dev call (1 024 000 query rows against the resident database, through
+    distributed.knn_frame_block_resident); here the 8 blocks of distributed.frames_of_rank run
+    one after the other on GPU 0.  Block 0: 512 sampled rows against the oracle; every block:
+    64 sampled rows, planted exact hits, and the properties that hold for every row."""
+    import torch
+    from poseestimation_amd.distributed import frames_of_rank, knn_frame_block_resident
+    lib = posehip.load()
+    n_frames, per_frame, world, nt = 4096, 2000, 8, 50_000
+    t = datagen.random_descriptors(nt, 300)
+    h = C.c_void_p()
+    posehip.check(lib.ph_db_upload(t.ctypes.data_as(C.POINTER(C.c_uint8)), nt, 32, C.byref(h)))
+    try:
+        covered = 0
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for rank in range(world):
+                frames = frames_of_rank(n_frames, world, rank)
+                assert len(frames) == 512 and frames[0] == covered
+                covered += len(frames)
+                rows = len(frames) * per_frame
+                # this block's frames, generated per block (the whole job is 262 MB of rows)
+                q = datagen.random_descriptors(rows, 301 + rank)
+                first = np.arange(len(frames)) * per_frame        # first row of every frame:
+                hit = (np.asarray(frames) * 12 + 5) % nt          # an exact copy of a database row
+                q[first] = t[hit]
+                d_q = _dev(q)
+                idx, dist, keep = knn_frame_block_resident(h, d_q, 2, ratio=0.75)
+                torch.cuda.current_stream().synchronize()
+                idx, dist, keep = idx.cpu().numpy(), dist.cpu().numpy(), keep.cpu().numpy()
+                assert (dist[first, 0] == 0).all() and (idx[first, 0] == hit).all()
+                assert keep[first].all()
+                assert (dist[:, 0] <= dist[:, 1]).all() and (idx[:, 0] != idx[:, 1]).all()
+                assert idx.min() >= 0 and idx.max() < nt
+                n_sample = 512 if rank == 0 else 64
+                pick = np.random.default_rng(rank).choice(rows, n_sample, replace=False)
+                oi, od = orc.knn(q[pick], t, 2, threads=8)
+                assert np.array_equal(idx[pick], oi) and np.array_equal(dist[pick], od)
+                kept = {m[0] for m in orc.ratio_filter(oi, od, 0.75)}
+                assert set(np.nonzero(keep[pick])[0].tolist()) == kept
+                sel = np.random.default_rng(100 + rank).choice(rows, 4096, replace=False)
+                for r in range(2):   # reported distances are those of the reported rows
+                    true = np.unpackbits(q[sel] ^ t[idx[sel, r]], axis=1).sum(axis=1)
+                    assert np.array_equal(true, dist[sel, r])
+                del d_q
+        assert covered == n_frames
+    finally:
+        posehip.check(lib.ph_db_free(h))

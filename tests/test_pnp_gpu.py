@@ -410,3 +410,78 @@ def test_solvepnp_ransac_many_correspondences(posehip, n):
     assert ok and ok0 and len(inl0) > 0.6 * n
     assert np.array_equal(inl.ravel(), inl0)
     assert_same_pose(rvec, tvec, r0, t0)
+
+
+def test_rows_on_the_threshold_circle_and_at_zero_depth(posehip):
+    """The scoring kernel settles most (row, model) verdicts in packed fp32 with an error
+    bound and falls back to the exact evaluation where the bound cannot decide.  Here the
+    fallback is forced deterministically: rows that no sample uses are moved so that, for one
+    model each, their reprojection lands on the threshold circle to within float rounding
+    (and one ulp either side of it), or their depth in the camera frame is ~0, 0 or slightly
+    negative.  Two problems with an ODD hypothesis count go down in one batched call, so that
+    a wave's pair of hypotheses also straddles the two problems.  Every count must equal the
+    oracle's."""
+    import torch
+    dev = torch.device("cuda", 0)
+    K = datagen.CAMERA_K
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    H, thr = 65, 8.0
+    objs, imgs, subs = [], [], []
+    for p, n in enumerate([2000, 1501]):
+        obj, img, _, _, _ = datagen.pnp_scene(n=n, seed=70 + p, angle_deg=25.0 + 20 * p)
+        sub = orc.ransac_subsets(n, H, rng_state=77 + p)
+        models, _ = orc.pnp_hypotheses(obj, img, K, sub)    # the rows below are in no sample,
+        free = np.setdiff1d(np.arange(n), sub.ravel())       # so the models stay what they are
+        usable = [h for h in range(H) if np.isfinite(models[h]).all()]
+        rng = np.random.default_rng(90 + p)
+        for j, row in enumerate(free):
+            m = models[usable[j % len(usable)]]
+            R, t = orc.rodrigues(m[:3]), m[3:]
+            if j % 5 == 4:      # a point at (almost) no depth for this model
+                eps = [1e-7, -1e-7, 1e-30, 0.0, 3e-5][(j // 5) % 5]
+                cam = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), eps])
+                obj[row] = (R.T @ (cam - t)).astype(np.float32)
+                continue
+            X = obj[row].astype(np.float64)
+            c = R @ X + t
+            u = np.array([fx * c[0] / c[2] + cx, fy * c[1] / c[2] + cy])
+            th = rng.uniform(0, 2 * np.pi)
+            px = (u + thr * np.array([np.cos(th), np.sin(th)])).astype(np.float32)
+            step = [0, 1, -1, 2][j % 4]      # on the circle, and an ulp or two off it
+            for _ in range(abs(step)):
+                px[0] = np.nextafter(px[0], np.float32(np.inf if step > 0 else -np.inf))
+            img[row] = px
+        objs.append(obj)
+        imgs.append(img)
+        subs.append(sub)
+    sizes = [o.shape[0] for o in objs]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    d_obj = torch.from_numpy(np.concatenate(objs)).to(dev)
+    d_img = torch.from_numpy(np.concatenate(imgs)).to(dev)
+    d_sub = torch.from_numpy(np.concatenate(subs)).to(dev)
+    d_off = torch.from_numpy(offsets).to(dev)
+    d_models = torch.zeros((2 * H, 6), dtype=torch.float64, device=dev)
+    d_counts = torch.zeros(2 * H, dtype=torch.int32, device=dev)
+    Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+    torch.cuda.synchronize()
+    posehip.check(posehip.load().ph_ransac_epnp_hypotheses_batched_dev(
+        d_obj.data_ptr(), d_img.data_ptr(), d_off.data_ptr(), 2,
+        Kc.ctypes.data_as(C.POINTER(C.c_double)), d_sub.data_ptr(), H, thr, d_models.data_ptr(),
+        d_counts.data_ptr(), None))
+    posehip.check(posehip.load().ph_stream_synchronize(None))
+    models, counts = d_models.cpu().numpy(), d_counts.cpu().numpy()
+    on_circle = 0
+    for p in range(2):
+        rm, rc = orc.pnp_hypotheses(objs[p], imgs[p], K, subs[p])
+        assert np.array_equal(counts[p * H:(p + 1) * H], rc)
+        assert_models_equal(models[p * H:(p + 1) * H], rm)
+        # the construction did put rows on the circle: for a usable model, some row's exact
+        # squared error is within 1e-4 of thr^2 (the fp32 pass's bound is far wider than that)
+        h = next(h for h in range(H) if np.isfinite(rm[h]).all())
+        R, t = orc.rodrigues(rm[h][:3]), rm[h][3:]
+        c = objs[p].astype(np.float64) @ R.T + t
+        with np.errstate(all="ignore"):
+            u = np.stack([fx * c[:, 0] / c[:, 2] + cx, fy * c[:, 1] / c[:, 2] + cy], axis=1)
+            err = ((u - imgs[p]) ** 2).sum(axis=1)
+        on_circle += int((np.abs(err - thr * thr) < 1e-4 * thr * thr).sum())
+    assert on_circle >= 10
