@@ -22,9 +22,12 @@
  *     (NULL = the library's own stream) and return after enqueueing unless
  *     stated otherwise;
  *   - descriptors are 256-bit ORB rows: 32 bytes each, row stride >= 32;
- *   - calls are serialised per process by an internal mutex and may come from
- *     any thread (the reference calls from a std::async worker,
- *     src/cereal_box.cpp:280).
+ *   - calls may come from any thread (the reference calls from a std::async
+ *     worker, src/cereal_box.cpp:280).  Every call runs in a context: the
+ *     default one of ph_init, or one made with ph_ctx_create and bound to the
+ *     calling thread with ph_ctx_make_current.  Calls through one context are
+ *     serialised by its lock; calls through different contexts run concurrently
+ *     (own stream, own workspace), on the same GPU or on different ones.
  */
 #ifndef POSEHIP_H
 #define POSEHIP_H
@@ -64,8 +67,38 @@ typedef struct {
 ph_status ph_init(int device);
 void ph_shutdown(void);
 const char *ph_last_error_string(void);
-/* Device the library is bound to, or -1. */
+/* Device of the calling thread's context (the default one unless
+ * ph_ctx_make_current bound another), or -1. */
 int ph_device(void);
+
+/* ---- more than one GPU, or more than one caller, in one process ------------ */
+/* The reference is one process with worker threads (src/cereal_box.cpp:280) and has
+ * no notion of a device; a host like it that deals frames to the 8 GPUs of a node
+ * needs one binding per GPU.  A context is such a binding: its own stream,
+ * workspace, staging buffers, settings (k-NN path, profiling) and lock.  ph_init
+ * creates the default context; ph_ctx_create makes another on any GPU, also on one
+ * that already has a context (two workers sharing a GPU then overlap instead of
+ * queueing behind one lock).
+ *
+ * Every ph_* entry point acts on the calling thread's CURRENT context:
+ * ph_ctx_make_current(ctx) binds one to the calling thread (like hipSetDevice, the
+ * binding is per thread), ph_ctx_make_current(NULL) returns the thread to the
+ * default context.  A worker thread per GPU therefore calls ph_ctx_make_current
+ * once and then uses the same entry points as single-GPU code.  Device pointers and
+ * streams passed to a call must belong to the context's GPU.  A resident train set
+ * (ph_db_upload) belongs to the context that uploaded it, is released with it, and
+ * serves calls of every context on the same GPU.
+ *
+ * ph_ctx_destroy waits for calls in flight through the context, then releases what
+ * it holds; threads that still have it current get PH_ERR_INVALID_ARG from their
+ * next call.  ph_shutdown releases the default context only.  The scratch of the
+ * allocation-free entry point is per GPU, not per context. */
+typedef struct ph_ctx ph_ctx;
+ph_status ph_ctx_create(int device, ph_ctx **ctx);
+ph_status ph_ctx_destroy(ph_ctx *ctx);
+ph_status ph_ctx_make_current(ph_ctx *ctx);
+ph_ctx *ph_ctx_current(void);          /* NULL: the default context */
+int ph_ctx_device(const ph_ctx *ctx);  /* -1 for a dead handle */
 
 /* ---- descriptor matching, host buffers ----------------------------------- */
 

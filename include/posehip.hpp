@@ -44,6 +44,36 @@ inline void check(ph_status s)
         throw Error(s, ph_last_error_string());
 }
 
+// A binding of the library to one GPU beside the default one (ph_ctx_create): its own stream,
+// workspace and lock.  No counterpart in OpenCV or the reference, which know one device; a
+// host that deals frames to several GPUs -- or lets several workers share one -- creates one
+// per worker.  Released with the object.
+class Context {
+  public:
+    explicit Context(int device) { check(ph_ctx_create(device, &ctx_)); }
+    ~Context() { (void)ph_ctx_destroy(ctx_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    ph_ctx *handle() const { return ctx_; }
+    int device() const { return ph_ctx_device(ctx_); }
+
+  private:
+    ph_ctx *ctx_ = nullptr;
+};
+
+// Binds a context to the calling thread for the guard's lifetime: every posehip call of the
+// thread (BFMatcher::match, solvePnPRansac, the C entry points) then runs in it.
+class CurrentContext {
+  public:
+    explicit CurrentContext(const Context &c) : before_(ph_ctx_current()) { check(ph_ctx_make_current(c.handle())); }
+    ~CurrentContext() { (void)ph_ctx_make_current(before_); }
+    CurrentContext(const CurrentContext &) = delete;
+    CurrentContext &operator=(const CurrentContext &) = delete;
+
+  private:
+    ph_ctx *before_;
+};
+
 // cv::DMatch, field for field (16 bytes).
 struct DMatch {
     int queryIdx = -1;

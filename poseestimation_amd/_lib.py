@@ -38,6 +38,11 @@ SIGNATURES = {
     "ph_shutdown": (None, []),
     "ph_last_error_string": (C.c_char_p, []),
     "ph_device": (C.c_int, []),
+    "ph_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ph_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "ph_ctx_make_current": (C.c_int, [C.c_void_p]),
+    "ph_ctx_current": (C.c_void_p, []),
+    "ph_ctx_device": (C.c_int, [C.c_void_p]),
     "ph_knn_hamming256": (C.c_int, [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int, C.c_size_t, C.c_int,
                                     _i32p, _i32p]),
     "ph_match_hamming256": (C.c_int, [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int, C.c_size_t, _dmp,

@@ -30,6 +30,8 @@
 // settles almost every (row, model) verdict and the exact fp64 evaluation runs only for
 // the batches it cannot settle; the inlier count is reduced with ballot + popcount.
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <float.h>
 #include <stdint.h>
 
@@ -2373,7 +2375,7 @@ static hipError_t launch_solve_split(const float *d_obj, const float *d_img, Cam
     return hipGetLastError();
 }
 
-static int g_solve_variant = 0;
+static std::atomic<int> g_solve_variant{0}; // a process-wide measurement setting, read by every context
 
 void ransac_set_solve_variant(int variant) { g_solve_variant = variant; }
 int ransac_solve_variant() { return g_solve_variant; }
