@@ -207,6 +207,61 @@ struct SubsetCache {
         return e.subs.data();
     }
 };
+
+// RANSACUpdateNumIters, in two parts: the two logarithms (the only libm calls) and the rule on
+// them.  The lone-call path hands the logarithms to the GPU as a table over every possible
+// inlier count and lets the refit kernel apply the rule (replay_update_iters in
+// ransac_epnp.hip: the same product, comparison, quotient and rounding).
+double iters_num_log(double p)
+{
+    p = std::max(p, 0.);
+    p = std::min(p, 1.);
+    return std::log(std::max(1. - p, DBL_MIN));
+}
+
+// log(1 - (1 - ep)^model_points), or NaN where the rule returns 0 (no outliers left).
+double iters_denom_log(double ep, int model_points)
+{
+    ep = std::max(ep, 0.);
+    ep = std::min(ep, 1.);
+    const double denom = 1. - std::pow(1. - ep, model_points);
+    if (denom < DBL_MIN)
+        return std::nan("");
+    return std::log(denom);
+}
+
+int update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    const double num = iters_num_log(p), denom = iters_denom_log(ep, model_points);
+    if (denom != denom)
+        return 0;
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
+}
+
+// iters_denom_log for every inlier count 0..n of a problem of n correspondences, kept across
+// calls per n (a video's frames repeat a few hundred distinct counts; the first call with a
+// new n pays n pow + log evaluations, about 50 ns each).
+struct IterTableCache {
+    size_t bytes = 0;
+    std::unordered_map<int, std::vector<double>> by_n;
+    const double *get(int n, int model_points)
+    {
+        if (bytes > ((size_t)64 << 20)) {
+            by_n.clear();
+            bytes = 0;
+        }
+        auto it = by_n.find(n);
+        if (it == by_n.end()) {
+            std::vector<double> t((size_t)n + 1);
+            for (int g = 0; g <= n; g++)
+                t[(size_t)g] = iters_denom_log((double)(n - g) / n, model_points);
+            bytes += t.size() * sizeof(double);
+            it = by_n.emplace(n, std::move(t)).first;
+        }
+        return it->second.data();
+    }
+};
+
 } // namespace
 
 // One binding of the library to a GPU: stream, workspace, staging buffers, settings and the
@@ -216,6 +271,7 @@ struct ph_ctx {
     std::mutex mu;              // held for the duration of every call through this context
     std::atomic<int> users{0};  // calls that have picked this context (ph_ctx_destroy waits for 0)
     SubsetCache subsets;        // RANSAC sample sequences, per (seed, correspondence count)
+    IterTableCache iter_tables; // RANSAC budget-rule logarithms, per correspondence count
     bool ready = false;
     int device = -1;
     int n_cus = 256;
@@ -230,6 +286,7 @@ struct ph_ctx {
     PinBuf h_in, h_out;     // host entry points: pinned gather buffer / zero-copy results
     DevBuf pnp_idx;         // RANSAC-EPnP: inlier rows of the refit
     DevBuf pnp_front;       // RANSAC-EPnP: hand-over between the two solve kernels (one round)
+    DevBuf pnp_hyp;         // RANSAC-EPnP, lone call: models | counts of its hypotheses
     // Frame-offset tables of batched calls travel through a small ring of pinned
     // slots (one asynchronous copy each; a slot is reused once its call has finished).
     struct OffsetSlot {
@@ -748,22 +805,6 @@ ph_status knn_frames_locked(Context &c, const FrameSide &q, const FrameSide &t, 
 }
 
 
-// RANSACUpdateNumIters.
-int update_num_iters(double p, double ep, int model_points, int max_iters)
-{
-    p = std::max(p, 0.);
-    p = std::min(p, 1.);
-    ep = std::max(ep, 0.);
-    ep = std::min(ep, 1.);
-    double num = std::max(1. - p, DBL_MIN);
-    double denom = 1. - std::pow(1. - ep, model_points);
-    if (denom < DBL_MIN)
-        return 0;
-    num = std::log(num);
-    denom = std::log(denom);
-    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
-}
-
 ph_status check_pnp_args(const void *obj, const void *img, int n, const double *K)
 {
     if (n < 0 || (n > 0 && (!obj || !img)) || !K)
@@ -797,8 +838,8 @@ void context_teardown(Context &c)
 {
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize(); // callers' streams may still hold work that uses the workspace
-    DevBuf *all[] = {&c.part,  &c.part2, &c.best,    &c.tmp_i,    &c.tmp_d,
-                     &c.d_in,  &c.pnp_idx, &c.xt,    &c.pnp_front};
+    DevBuf *all[] = {&c.part,  &c.part2,   &c.best, &c.tmp_i,     &c.tmp_d,
+                     &c.d_in,  &c.pnp_idx, &c.xt,   &c.pnp_front, &c.pnp_hyp};
     for (DevBuf *b : all)
         b->release();
     c.h_in.release();
@@ -1952,8 +1993,90 @@ ph_status ph_solvepnp_ransac_epnp(const float *obj, const float *img, int n, con
         return PH_OK;
     }
 
-    // The subset sequence is model-independent, so all hypotheses of the budget
-    // are solved and scored in parallel, in chunks; OpenCV's sequential rule
+    // A budget of one chunk on a problem of moderate size (the reference's per-frame call is
+    // 100 iterations on a few hundred pairs) runs WITHOUT a host round trip: solve and score
+    // every hypothesis of the budget, then one more launch that replays OpenCV's sequential
+    // selection rule over the device-resident counts (strictly larger count wins, every win
+    // shrinks the budget), lists the chosen model's inliers and refits on them.  One copy in,
+    // three launches, one synchronisation.  The rule's logarithms come from this host (a
+    // table over every possible inlier count, cached per problem size), so the iteration
+    // count and the chosen hypothesis are those of the host replay below, bit for bit.
+    constexpr int FUSED_MAX_HYPOTHESES = 4096, FUSED_MAX_ROWS = 4096;
+    if (std::max(iterations_count, 1) <= FUSED_MAX_HYPOTHESES && n <= FUSED_MAX_ROWS) {
+        const int total = std::max(iterations_count, 1);
+        const int32_t *subs = c.subsets.get(rng_state, n, total);
+        const double *table = c.iter_tables.get(n, model_points);
+        // pinned input area: obj | img | subsets | table, moved with one copy
+        const size_t img_off = align256((size_t)n * 12), sub_off = img_off + align256((size_t)n * 8);
+        const size_t tab_off = sub_off + align256((size_t)total * 5 * sizeof(int32_t));
+        const size_t in_total = tab_off + ((size_t)n + 1) * sizeof(double);
+        PH_HIP(c.h_in.reserve(in_total));
+        PH_HIP(c.d_in.reserve(in_total));
+        uint8_t *h = (uint8_t *)c.h_in.p;
+        memcpy(h, obj, (size_t)n * 12);
+        memcpy(h + img_off, img, (size_t)n * 8);
+        memcpy(h + sub_off, subs, (size_t)total * 5 * sizeof(int32_t));
+        memcpy(h + tab_off, table, ((size_t)n + 1) * sizeof(double));
+        PH_HIP(hipMemcpyAsync(c.d_in.p, h, in_total, hipMemcpyHostToDevice, st));
+        const uint8_t *din = (const uint8_t *)c.d_in.p;
+        const float *d_obj = (const float *)din, *d_img = (const float *)(din + img_off);
+        // device-resident hypotheses: models | counts
+        const size_t cnt_off = align256((size_t)total * 6 * sizeof(double));
+        PH_HIP(c.pnp_hyp.reserve(cnt_off + (size_t)total * sizeof(int32_t)));
+        double *d_models = (double *)c.pnp_hyp.p;
+        int32_t *d_counts = (int32_t *)((uint8_t *)c.pnp_hyp.p + cnt_off);
+        PH_HIP(c.pnp_idx.reserve((size_t)n * sizeof(int32_t)));
+        // pinned results, written by the last kernel: refit model | inlier count | iterations,
+        // chosen hypothesis | inlier list
+        const size_t ninl_off = 256, rep_off = 512, list_off = 768;
+        PH_HIP(c.h_out.reserve(list_off + (size_t)n * sizeof(int32_t)));
+        uint8_t *hb = (uint8_t *)c.h_out.p, *db = (uint8_t *)c.h_out.dp;
+        int32_t *h_rep = (int32_t *)(hb + rep_off);
+        h_rep[0] = 0;
+        h_rep[1] = -2; // overwritten by the kernel
+        PH_HIP(ransac_hypotheses_launch(d_obj, d_img, n, cam, (const int32_t *)(din + sub_off),
+                                        nullptr, nullptr, 1, total, thr2, d_models, d_counts,
+                                        c.n_cus, st));
+        RefitOne one{};
+        one.rows = n;
+        RefitReplay rp;
+        rp.counts = d_counts;
+        rp.models = d_models;
+        rp.iter_table = (const double *)(din + tab_off);
+        rp.num_log = iters_num_log(confidence);
+        rp.total = total;
+        rp.out = (int32_t *)(db + rep_off);
+        PH_HIP(epnp_refit_batched_launch(d_obj, d_img, nullptr, nullptr, nullptr, nullptr, one, 1,
+                                         cam, thr2, (int32_t *)c.pnp_idx.p,
+                                         (int32_t *)(db + list_off), (int32_t *)(db + ninl_off),
+                                         (double *)db, st, &rp));
+        PH_HIP(hipStreamSynchronize(st));
+        if (h_rep[1] == -2)
+            return fail(PH_ERR_HIP, "the refit kernel did not report its selection");
+        if (iterations_run)
+            *iterations_run = h_rep[0];
+        if (h_rep[1] < 0) { // no hypothesis with 5 or more inliers
+            *found = 0;
+            return PH_OK;
+        }
+        const int k = *(const int32_t *)(hb + ninl_off);
+        if (k < 4) { // cannot happen with a chosen model of >= 5 inliers
+            *found = 0;
+            return PH_OK;
+        }
+        const double *m6 = (const double *)hb;
+        memcpy(rvec, m6, 3 * sizeof(double));
+        memcpy(tvec, m6 + 3, 3 * sizeof(double));
+        if (inliers)
+            memcpy(inliers, hb + list_off, (size_t)k * sizeof(int32_t));
+        if (n_inliers)
+            *n_inliers = k;
+        *found = 1;
+        return PH_OK;
+    }
+
+    // Larger budgets and problems: the subset sequence is model-independent, so all hypotheses
+    // of the budget are solved and scored in parallel, in chunks; OpenCV's sequential rule
     // (strictly larger count wins, budget shrinks on every win) is then replayed
     // over the counts, and chunks beyond the shrunken budget are never launched.
     int niters = std::max(iterations_count, 1);

@@ -62,12 +62,30 @@ struct RefitOne {
     double best[6];
     int rows;
 };
+// With `replay` (single problem only: d_begins == nullptr) the kernel first chooses the model
+// itself, by OpenCV's sequential selection rule over the device-resident inlier counts of the
+// call's hypotheses (strictly larger count wins, every win shrinks the iteration budget by
+// RANSACUpdateNumIters), so that a lone solvePnPRansac needs no host round trip between
+// scoring and refit.  iter_table[g] = log(1 - (g / rows)^5) as the HOST's libm computes it
+// (NaN where the host's rule returns 0), num_log = log(max(1 - confidence, DBL_MIN)): the
+// device only multiplies, compares, divides and rounds, each bit-identical to the host's.
+// out[0] = iterations the sequential loop would have run, out[1] = index of the chosen
+// hypothesis or -1 (then d_n_inliers[0] = 0 and nothing else is written).
+struct RefitReplay {
+    const int32_t *counts = nullptr; // [total] inlier counts, in hypothesis order
+    const double *models = nullptr;  // [total][6]
+    const double *iter_table = nullptr; // [rows + 1]
+    double num_log = 0;
+    int total = 0;
+    int32_t *out = nullptr;
+};
 hipError_t epnp_refit_batched_launch(const float *d_obj, const float *d_img,
                                      const int32_t *d_begins, const int32_t *d_ends,
                                      const double *d_best_models, const uint8_t *d_use_all_rows,
                                      const RefitOne &one, int n_problems, CameraK K, float thr2,
                                      int32_t *d_idx,
                                      int32_t *d_idx_out, int32_t *d_n_inliers,
-                                     double *d_models_out, hipStream_t stream);
+                                     double *d_models_out, hipStream_t stream,
+                                     const RefitReplay *replay = nullptr);
 
 } // namespace posehip

@@ -2248,16 +2248,77 @@ __global__ __launch_bounds__(64 * REFIT_WAVES) void epnp_solve_kernel(
 // values to the same words), so none waits for another before its solve.
 // begins == nullptr: one problem, rows 0..one.rows, model one.best (passed by value: a
 // single call then reads no table).
+// RANSACUpdateNumIters with the two libm results it needs taken from the host (num_log =
+// log(max(1 - confidence, DBL_MIN)), denom_log = log(1 - (good / n)^5), NaN where the host's
+// rule returns 0), so that the product, the comparison, the correctly rounded quotient and the
+// round-to-nearest-even are the host's own operations on the host's own operands.
+__device__ __forceinline__ int replay_update_iters(double denom_log, double num_log, int max_iters)
+{
+    if (denom_log != denom_log)
+        return 0;
+    if (denom_log >= 0 || -num_log >= max_iters * (-denom_log))
+        return max_iters;
+    return (int)__builtin_rint(num_log / denom_log);
+}
+
+// RANSACPointSetRegistrator::run's selection rule over the inlier counts of `total` hypotheses,
+// in their order: a hypothesis wins iff it lies inside the current budget and its count is
+// strictly larger than every earlier winner's and than 4; each win shrinks the budget.  The
+// whole wave runs it together, 64 counts at a time; every lane returns the same values.
+// Returns the index of the last winner (-1: none); run = iterations the sequential loop
+// would have gone through.
+__device__ __forceinline__ int replay_selection(const RefitReplay &rp, int lane, int &run)
+{
+    int niters = rp.total, max_good = 4, best = -1;
+    for (int base = 0; base < niters; base += 64) {
+        const int i = base + lane;
+        const int c = i < rp.total ? rp.counts[i] : 0;
+        unsigned long long cand = __ballot(c > max_good && i < niters);
+        while (cand) {
+            const int p = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            if (base + p >= niters) // the budget has shrunk below this hypothesis: the loop has ended
+                break;
+            const int cp = __shfl(c, p);
+            if (cp > max_good) {
+                max_good = cp;
+                best = base + p;
+                niters = replay_update_iters(rp.iter_table[cp], rp.num_log, niters);
+            }
+        }
+    }
+    run = niters > best + 1 ? niters : best + 1;
+    return best;
+}
+
 __global__ __launch_bounds__(64 * REFIT_WAVES) void epnp_refit_batched_kernel(
     const float *__restrict__ obj, const float *__restrict__ img,
     const int32_t *__restrict__ begins, const int32_t *__restrict__ ends,
     const double *__restrict__ best_models, const uint8_t *__restrict__ use_all_rows,
-    RefitOne one, CameraK K, float thr2, int32_t *idx_dev, int32_t *__restrict__ idx_out,
-    int32_t *__restrict__ n_inliers, double *__restrict__ models_out)
+    RefitOne one, RefitReplay replay, CameraK K, float thr2, int32_t *idx_dev,
+    int32_t *__restrict__ idx_out, int32_t *__restrict__ n_inliers,
+    double *__restrict__ models_out)
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x;
+    // a lone call whose hypotheses were scored on the device: choose the model here (every wave
+    // for itself, with the same result), instead of on the host between two synchronisations
+    const double *chosen = nullptr;
+    if (!begins && replay.counts) {
+        int run;
+        const int best = replay_selection(replay, lane, run);
+        if (threadIdx.x == 0) {
+            replay.out[0] = run;
+            replay.out[1] = best;
+        }
+        if (best < 0) { // no hypothesis with 5 or more inliers: no pose
+            if (threadIdx.x == 0)
+                n_inliers[0] = 0;
+            return;
+        }
+        chosen = replay.models + (int64_t)best * 6;
+    }
     const int64_t row0 = begins ? begins[b] : 0;
     const int rows = begins ? ends[b] - begins[b] : one.rows;
     obj += 3 * row0;
@@ -2271,8 +2332,8 @@ __global__ __launch_bounds__(64 * REFIT_WAVES) void epnp_refit_batched_kernel(
         // constant indices: a loop over one.best would put the by-value struct in scratch
         double rv[3] = {one.best[0], one.best[1], one.best[2]};
         double tv[3] = {one.best[3], one.best[4], one.best[5]};
-        if (begins) {
-            const double *m = best_models + (int64_t)b * 6;
+        if (begins || chosen) {
+            const double *m = begins ? best_models + (int64_t)b * 6 : chosen;
             rv[0] = m[0]; rv[1] = m[1]; rv[2] = m[2];
             tv[0] = m[3]; tv[1] = m[4]; tv[2] = m[5];
         }
@@ -2579,14 +2640,18 @@ hipError_t epnp_refit_batched_launch(const float *d_obj, const float *d_img,
                                      const RefitOne &one, int n_problems, CameraK K, float thr2,
                                      int32_t *d_idx,
                                      int32_t *d_idx_out, int32_t *d_n_inliers,
-                                     double *d_models_out, hipStream_t stream)
+                                     double *d_models_out, hipStream_t stream,
+                                     const RefitReplay *replay)
 {
     if (n_problems <= 0)
         return hipSuccess;
+    if (replay && (d_begins || n_problems != 1 || !replay->counts || !replay->models ||
+                   !replay->iter_table || !replay->out || replay->total < 1))
+        return hipErrorInvalidValue;
     const size_t lds_bytes = (size_t)REFIT_LDS_DOUBLES * sizeof(double);
     epnp_refit_batched_kernel<<<n_problems, 64 * REFIT_WAVES, lds_bytes, stream>>>(
-        d_obj, d_img, d_begins, d_ends, d_best_models, d_use_all_rows, one, K, thr2, d_idx,
-        d_idx_out, d_n_inliers, d_models_out);
+        d_obj, d_img, d_begins, d_ends, d_best_models, d_use_all_rows, one,
+        replay ? *replay : RefitReplay{}, K, thr2, d_idx, d_idx_out, d_n_inliers, d_models_out);
     return hipGetLastError();
 }
 

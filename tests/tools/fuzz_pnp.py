@@ -8,6 +8,26 @@ import numpy as np
 import datagen, oracle_bind as orc
 import poseestimation_amd as pa
 pa._lib.init(0)
+import ctypes as C
+_lib = pa._lib
+_K9 = np.ascontiguousarray(datagen.CAMERA_K, np.float64).reshape(9)
+
+
+def single_call(obj, img, iters, thr):
+    """ph_solvepnp_ransac_epnp on one problem (the lone-call path, which chooses the model on
+    the GPU): (found, rvec, tvec, inliers, iterations_run)."""
+    fp, dp, ip = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    n = obj.shape[0]
+    rvec, tvec, inl = np.zeros(3), np.zeros(3), np.empty(n, np.int32)
+    n_inl, found, it = C.c_int(0), C.c_int(0), C.c_int(0)
+    _lib.check(_lib.load().ph_solvepnp_ransac_epnp(
+        obj.ctypes.data_as(fp), img.ctypes.data_as(fp), n, _K9.ctypes.data_as(dp), iters, thr, 0.99,
+        0xFFFFFFFFFFFFFFFF, rvec.ctypes.data_as(dp), tvec.ctypes.data_as(dp), inl.ctypes.data_as(ip),
+        C.byref(n_inl), C.byref(found), C.byref(it)))
+    return bool(found.value), rvec, tvec, inl[:n_inl.value], it.value
+
+
+n_single = 0
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end, n_prob, worst = time.time() + budget, 0, 0.0
@@ -42,4 +62,17 @@ while time.time() < t_end:
                 worst = max(worst, e)
                 assert e <= 1e-4, (len(obj), iters, thr, e)
         n_prob += 1
-print({"problems": n_prob, "worst_relative_pose_difference": worst, "ok": True})
+    # the same problems, one call each (every third batch): equal to the batched call's result
+    if n_prob % 3 == 0:
+        for obj, img, (ok, rvec, tvec, inl, it) in zip(objs, imgs, res):
+            if len(obj) < 5:
+                continue
+            ok1, r1, t1, inl1, it1 = single_call(obj, img, iters, thr)
+            assert ok1 == ok, (len(obj), iters, thr, ok1, ok)
+            if len(obj) > 5:
+                assert it1 == it, (len(obj), iters, thr, it1, it)
+            if ok:
+                assert np.array_equal(inl1, inl.ravel()), (len(obj), iters, thr)
+                assert np.abs(r1 - rvec.ravel()).max() <= 1e-12 and np.abs(t1 - tvec.ravel()).max() <= 1e-12
+            n_single += 1
+print({"problems": n_prob, "single_calls": n_single, "worst_relative_pose_difference": worst, "ok": True})
