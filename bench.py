@@ -424,6 +424,8 @@ def bench_train_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr):
 
 def main():
     args = parse()
+    # RCCL shares buffers between the ranks' processes through dmabuf handles on this platform
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     import torch

@@ -151,3 +151,26 @@ def test_noalloc_under_graph_capture(posehip, mode, nq, nt):
         assert torch.equal(idx, ri) and torch.equal(dist, rd) and torch.equal(keep, rk)
     finally:
         lib.ph_knn_set_path(0)
+
+
+def test_noalloc_makes_no_allocating_hip_call():
+    """The same two-calls-in-a-row check with every allocator entry point of the HIP runtime
+    interposed and COUNTED (tests/noalloc_probe.cpp: the executable defines hipMalloc, hipFree,
+    hipHostMalloc, ... itself, so the library's calls land in it): zero allocating or freeing
+    calls while the allocation-free entry point runs, on either distance kernel, and results
+    equal to the allocating entry point's.  A free-memory delta cannot see pooled or sub-page
+    allocations; a call count can.  Runs in a process of its own (no torch allocator)."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "noalloc_probe")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["ok"] is True
+    assert line["allocating_calls_of_the_control"] > 0      # the interposition is live
+    assert line["noalloc_calls"] == 6
+    assert line["allocations_during_them"] == 0 and line["frees_during_them"] == 0
+    assert line["equal_to_allocating_entry_point"] is True
