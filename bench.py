@@ -196,17 +196,43 @@ def ransac_roofline(args, torch, lib, _lib, step, problems, hyps, n_points):
     score_ms = float(np.mean(score))
     traffic = None   # HBM bytes per solve launch from the PMC passes of the same shape
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_ransac_16x4096x2000.json")))
+        pmc_path = os.path.join(ROOT, "profiles", "r03", "pmc_ransac_16x4096x2000.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", "r02", "pmc_ransac_16x4096x2000.json")
+        pmc = json.load(open(pmc_path))
         if (hyps, n_points) == (4096, 2000) and problems * hyps >= n_cus * 128 == 256 * 128:  # full rounds
             traffic = pmc["derived"]["void posehip::ransac_solve_kernel<32>"]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
+    # One wave per SIMD is all the solve's registers and LDS allow, and a lone wave cannot
+    # issue fp64 instructions as fast as the pipe takes them from eight: the ratio of the two
+    # measured issue intervals (independent mul+add chains, tools/fp64_rate) scales the
+    # no-fma rate down to what a single wave per SIMD can reach at all.
+    lone, full = 7.16, 4.54
+    try:
+        rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r02",
+                                                         "fp64_issue_rate_by_waves.jsonl"))]
+        pick = {r["waves_per_simd"]: r["cycles_per_instr_per_simd"] for r in rows
+                if r["op"] == "mul+add" and r["chains"] == 4}
+        lone, full = pick[1], pick[8]
+    except Exception:
+        pass
+    single_wave_ceiling = mix.value * full / lone
     return {
         "bound": "fp64 valu",
         "kernel": "ransac_solve_kernel<32>",
         "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
         "frac": achieved / peak,
         "frac_of_mul_add_rate": achieved / mix.value,
+        "frac_of_single_wave_ceiling": achieved / single_wave_ceiling,
+        "single_wave_ceiling_TFLOPs": single_wave_ceiling / 1e12,
+        "single_wave_ceiling_note": f"no-fma rate x {full:.2f} / {lone:.2f}: clocks per fp64 "
+                                    f"instruction of a SIMD with eight waves against one wave "
+                                    f"(profiles/r02/fp64_issue_rate_by_waves.jsonl); the kernel "
+                                    f"runs one wave per SIMD (424 registers, LDS for 128 "
+                                    f"hypotheses per CU), and about half of its instructions "
+                                    f"are algorithmic operations (the rest expand correctly "
+                                    f"rounded quotients and roots, select and address)",
         "traffic": traffic,
         "kernel_ms": solve_ms,
         "kernel_ms_with_scoring_underneath": float(np.mean(last)) if n_rounds > 1 else None,

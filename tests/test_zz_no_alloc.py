@@ -153,6 +153,31 @@ def test_noalloc_under_graph_capture(posehip, mode, nq, nt):
         lib.ph_knn_set_path(0)
 
 
+def test_noalloc_call_does_not_leave_stale_profiling_events(posehip):
+    """With profiling on, a k-NN call records events around its kernels; the allocation-free
+    entry point records none, so after it the timing query must say so instead of pairing
+    the earlier call's events with the later call's kernel."""
+    import ctypes as C
+    lib = posehip.load()
+    d_q, d_t = _dev(datagen.random_descriptors(600, 1)), _dev(datagen.random_descriptors(900, 2))
+    a, b = C.c_float(-1), C.c_float(-1)
+    posehip.check(lib.ph_set_profiling(1))
+    try:
+        posehip.check(lib.ph_knn_set_path(1))
+        _call(posehip, "ph_knn_hamming256_dev", d_q, d_t, 2, 0, None)          # popcount kernel, profiled
+        posehip.check(lib.ph_knn_last_timing(C.byref(a), C.byref(b)))
+        assert a.value > 0
+        posehip.check(lib.ph_knn_set_path(2))
+        _call(posehip, "ph_knn_hamming256_noalloc_dev", d_q, d_t, 2, 0, None)  # matrix cores, no events
+        assert lib.ph_knn_last_path() == 1
+        assert lib.ph_knn_last_timing(C.byref(a), C.byref(b)) == 1
+        assert b"no profiled" in lib.ph_last_error_string()
+        assert lib.ph_knn_last_prepass_timing(C.byref(a)) == 1
+    finally:
+        lib.ph_knn_set_path(0)
+        lib.ph_set_profiling(0)
+
+
 def test_noalloc_makes_no_allocating_hip_call():
     """The same two-calls-in-a-row check with every allocator entry point of the HIP runtime
     interposed and COUNTED (tests/noalloc_probe.cpp: the executable defines hipMalloc, hipFree,

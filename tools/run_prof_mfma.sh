@@ -1,10 +1,12 @@
 # Profiles of the matrix-core matcher at the bench shape (F frames of 10k x 10k, F = $1 or 64):
 # kernel trace of bench.py, then HBM-traffic and SQ counter passes on tools/knn_time.
+# usage: bash tools/run_prof_mfma.sh [F] [tag]   (raw output under gpurun_out/prof_<tag>_F<F>; tag r01m by default)
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 F=${1:-64}
-O=$R/gpurun_out/prof_r01m_F$F
+TAG=${2:-r01m}
+O=$R/gpurun_out/prof_${TAG}_F$F
 mkdir -p $O
 timeout -k 10 300 python3 bench.py --frames-per-step $F > $O/bench_line.json 2> $O/bench.err
 cd /tmp

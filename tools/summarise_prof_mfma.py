@@ -1,7 +1,9 @@
 """Turns the raw output of tools/run_prof_mfma.sh (gpurun_out/prof_r01m_F<F>/) into the
 summaries kept under profiles/r01/ and the traffic entry bench.py reads.
-    python tools/summarise_prof_mfma.py 64 [--primary]
---primary: also copy the kernel-trace summary and the bench lines (the shape bench.py runs)."""
+    python tools/summarise_prof_mfma.py 64 [--primary] [--tag r03m --round r03]
+--primary: also copy the kernel-trace summary and the bench lines (the shape bench.py runs).
+--tag / --round: the raw directory's tag (tools/run_prof_mfma.sh's second argument) and the
+directory under profiles/ the summaries go to (r01m / r01 by default)."""
 import collections
 import csv
 import glob
@@ -14,8 +16,11 @@ import sys
 F = int(sys.argv[1])
 primary = "--primary" in sys.argv
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(ROOT, "gpurun_out", f"prof_r01m_F{F}")
+TAG = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r01m"
+ROUND = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r01"
+O = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}_F{F}")
 P = os.path.join(ROOT, "profiles")
+os.makedirs(os.path.join(P, ROUND), exist_ok=True)
 
 
 def newest(pat):
@@ -73,17 +78,23 @@ summary = {
         "roofline_frac": bench["roofline"]["frac"], "kernel_ms": bench["roofline"]["kernel_ms"],
         "prepass_ms": bench["roofline"]["prepass_ms"], "merge_kernel_ms": bench["roofline"]["merge_kernel_ms"]},
 }
-json.dump(summary, open(os.path.join(P, "r01", f"pmc_knn_mfma_frames_{F}x10k_x_10k.json"), "w"), indent=1)
+json.dump(summary, open(os.path.join(P, ROUND, f"pmc_knn_mfma_frames_{F}x10k_x_10k.json"), "w"), indent=1)
 t = json.load(open(os.path.join(P, "hbm_traffic.json")))
 t.setdefault("knn_mfma_frames_kernel_bytes_per_launch_by_frames", {})[str(F)] = int(
     summary["derived_knn_mfma_frames_kernel"]["hbm_bytes_per_launch"])
 if F == 16:
     t["knn_mfma_frames_kernel_bytes_per_launch"] = t["knn_mfma_frames_kernel_bytes_per_launch_by_frames"]["16"]
+if F == 64:
+    t["mfma_frames_64_how"] = (f"tools/run_prof_mfma.sh 64 {TAG} (profiles/{ROUND}/pmc_knn_mfma_frames_64x10k_x_10k.json): "
+                               f"64 frames per launch, one split, the distance kernel writes the k-NN rows itself; "
+                               f"algorithmic bytes = 20.48 MB of raw query rows + 81.92 MB of train image read once + "
+                               f"10.24 MB of k-NN rows (idx, dist: 16 B per query) written once = 112.6 MB")
+    t["mfma_frames_64_algorithmic_compulsory_bytes"] = alg
 json.dump(t, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
 if primary:
-    shutil.copy(newest("kt/vm/*_kernel_stats.csv"), os.path.join(P, "r01", "bench_kernel_stats_mfma.csv"))
-    shutil.copy(os.path.join(O, "bench_under_rocprof.json"), os.path.join(P, "r01", "bench_under_rocprof_mfma.json"))
-    shutil.copy(os.path.join(O, "bench_line.json"), os.path.join(P, "r01", "bench_line_mfma.json"))
+    shutil.copy(newest("kt/vm/*_kernel_stats.csv"), os.path.join(P, ROUND, "bench_kernel_stats_mfma.csv"))
+    shutil.copy(os.path.join(O, "bench_under_rocprof.json"), os.path.join(P, ROUND, "bench_under_rocprof_mfma.json"))
+    shutil.copy(os.path.join(O, "bench_line.json"), os.path.join(P, ROUND, "bench_line_mfma.json"))
 d = summary["derived_knn_mfma_frames_kernel"]
 print(json.dumps({k: d[k] for k in ("mfma_pipe_utilisation", "valu_instructions_per_mfma", "wave_time_split",
                                     "hbm_bytes_per_launch", "algorithmic_bytes_per_launch")}, indent=1))
