@@ -140,6 +140,45 @@ def check(status):
         raise PosehipError(status, load().ph_last_error_string().decode("utf-8", "replace"))
 
 
+class Context:
+    """A binding of the library to one GPU beside the default one (ph_ctx_create): its own
+    stream, workspace and lock.  No counterpart in cv2 or the reference, which know one
+    device; worker threads that share a GPU, or that each drive their own, create one each.
+
+        ctx = Context(device)
+        with ctx:                # ph_ctx_make_current for this thread, restored on exit
+            bf.match(q, t)       # every call of this thread now runs in ctx
+        ctx.close()              # ph_ctx_destroy (waits for calls in flight)
+    """
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(load().ph_ctx_create(int(device), C.byref(self._h)))
+        self._before = []
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def device(self):
+        return load().ph_ctx_device(self._h)
+
+    def __enter__(self):
+        self._before.append(load().ph_ctx_current())
+        check(load().ph_ctx_make_current(self._h))
+        return self
+
+    def __exit__(self, *exc):
+        load().ph_ctx_make_current(self._before.pop())
+        return False
+
+    def close(self):
+        if self._h:
+            check(load().ph_ctx_destroy(self._h))
+            self._h = C.c_void_p()
+
+
 def init(device=0):
     check(load().ph_init(int(device)))
 

@@ -208,3 +208,27 @@ def test_context_lifetime_and_shared_train_set(posehip):
     assert seen["status"] == 1 and b"destroyed" in seen["msg"]
     assert lib.ph_ctx_make_current(c) == 1       # cannot bind a dead handle
     assert lib.ph_ctx_create(99, C.byref(c)) == 1 and not c.value
+
+
+def test_python_context_wrapper(posehip):
+    """poseestimation_amd.Context: the mirror's calls run in the context while it is entered,
+    in the default context again afterwards, and a closed context cannot be entered."""
+    import poseestimation_amd as pa
+    lib = posehip.load()
+    q, t = datagen.random_descriptors(400, 21), datagen.perturbed_copy(datagen.random_descriptors(400, 21), 22)
+    want = orc.match(q, t, cross_check=True)
+    ctx = pa.Context(0)
+    assert ctx.device == 0 and lib.ph_ctx_current() is None
+    with ctx:
+        assert lib.ph_ctx_current() == ctx.handle.value
+        got = pa.BFMatcher(pa.NORM_HAMMING, crossCheck=True).match(q, t)
+        with pa.Context(0) as inner:          # nesting restores the outer binding
+            assert lib.ph_ctx_current() == inner.handle.value
+        assert lib.ph_ctx_current() == ctx.handle.value
+        inner.close()
+    assert lib.ph_ctx_current() is None
+    assert [(m.queryIdx, m.trainIdx, m.imgIdx, m.distance) for m in got] == want
+    ctx.close()
+    ctx.close()                               # idempotent
+    with pytest.raises(posehip.PosehipError):
+        ctx.__enter__()
