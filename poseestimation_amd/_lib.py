@@ -165,6 +165,8 @@ class Context:
         return load().ph_ctx_device(self._h)
 
     def __enter__(self):
+        if not self._h:
+            raise PosehipError(1, "this context has been closed")
         self._before.append(load().ph_ctx_current())
         check(load().ph_ctx_make_current(self._h))
         return self

@@ -1065,8 +1065,9 @@ const char *ph_last_error_string(void) { return g_err; }
 int ph_device(void)
 {
     std::lock_guard<std::mutex> lk(g_reg_mu);
-    Context *c = t_current && g_live.count(t_current) ? t_current : g_default;
-    return c ? c->device : -1;
+    if (t_current) // a context that has been destroyed under this thread serves no call: -1
+        return g_live.count(t_current) ? t_current->device : -1;
+    return g_default ? g_default->device : -1;
 }
 
 ph_status ph_stream_synchronize(void *stream)
