@@ -13,7 +13,9 @@ step on the popcount kernel (`popcount_kernel`) when the matrix cores ran it.
 `python bench.py --gpus N` started bare (no WORLD_SIZE in the environment) launches the N
 ranks itself, as child processes of a parent that never touches the GPU; under
 torch.distributed.run it is one of the ranks.  Beside the frame-sharded headline every
-run also times the train-sharded form of the matcher (BASELINE configs[4] scaled to the
+run also times BASELINE configs[3] as the frame-sharded job deals it (512 frames x 2000
+descriptors per rank against a resident 50k-row database: `frame_sharded_database`) and
+the train-sharded form of the matcher (BASELINE configs[4] scaled to the
 rank count: queries replicated, train rows in contiguous shards, one all-gather of the
 per-shard candidates, merge) and reports it as `train_sharded`.
 
@@ -68,6 +70,12 @@ def parse():
     ap.add_argument("--shard-nt", type=int, default=1_250_000,
                     help="train-sharded leg: train rows per rank (BASELINE configs[4]: 10M / 8)")
     ap.add_argument("--shard-steps", type=int, default=3)
+    ap.add_argument("--db-frames", type=int, default=512,
+                    help="frame-sharded leg: frames per rank (BASELINE configs[3]: 4096 / 8)")
+    ap.add_argument("--db-rows-per-frame", type=int, default=2000)
+    ap.add_argument("--db-rows", type=int, default=50_000,
+                    help="frame-sharded leg: rows of the model database resident on every rank")
+    ap.add_argument("--db-steps", type=int, default=5)
     return ap.parse_args()
 
 
@@ -448,6 +456,65 @@ def bench_train_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr):
     return res
 
 
+def bench_frame_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr):
+    """The frame-sharded form of BASELINE configs[3]: 4096 frames x 2000 descriptors against a
+    50k-row model database, 512 frames per rank at 8 ranks.  The database is uploaded once and
+    stays resident on every rank; a rank's block of frames is ONE search
+    (distributed.knn_frame_block_resident); nothing is exchanged.  Weak scaling: every rank
+    has its own 512 frames."""
+    F, R, T = args.db_frames, args.db_rows_per_frame, args.db_rows
+    if F <= 0 or R <= 0 or T <= 0:
+        return None
+    from poseestimation_amd.distributed import knn_frame_block_resident
+    g = torch.Generator(device=dev)
+    g.manual_seed(7000)
+    d_db = torch.randint(0, 256, (T, 32), dtype=torch.uint8, device=dev, generator=g)
+    g.manual_seed(7001 + rank)
+    d_q = torch.randint(0, 256, (F * R, 32), dtype=torch.uint8, device=dev, generator=g)
+    db_host = d_db.cpu().numpy()
+    h = C.c_void_p()
+    _lib.check(lib.ph_db_upload(db_host.ctypes.data_as(C.POINTER(C.c_uint8)), T, 32, C.byref(h)))
+    last = {}
+
+    def step():
+        last["out"] = knn_frame_block_resident(h, d_q, 2, ratio=args.ratio)
+
+    try:
+        _, (el, steps) = timed_region(step, args.db_steps, 1, 0.0, 0.0, torch, dist, dev, world,
+                                      args.dist_backend)
+        res = {
+            "value": float(F) * R * T * world * steps / el, "unit": "Hamming evals/s",
+            "steps": steps, "ms_per_step": el / steps * 1e3, "scaling": "weak",
+            "config": {"workload": f"{F * world} frames x {R} descriptors against a resident "
+                                   f"{T}-row model database, kNN k=2 + ratio {args.ratio} "
+                                   f"(BASELINE configs[3]: 4096 frames over 8 GPUs), {F} frames per "
+                                   f"rank in one search",
+                       "frames_per_rank": F, "rows_per_frame": R, "db_rows": T,
+                       "parallelism": f"frames x{world} (no collective)"},
+            "us_per_frame": el / steps / F * 1e6,
+        }
+        if rank == 0:
+            # spot check: sampled query rows through the plain device entry point on the raw rows
+            idx, dst, keep = last["out"]
+            pick = torch.randperm(F * R, device=dev,
+                                  generator=torch.Generator(device=dev).manual_seed(2))[:256]
+            sq = d_q[pick].contiguous()
+            ci = torch.empty((256, 2), dtype=torch.int32, device=dev)
+            cd = torch.empty((256, 2), dtype=torch.int32, device=dev)
+            ck = torch.empty(256, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            _lib.check(lib.ph_knn_hamming256_dev(sq.data_ptr(), 256, d_db.data_ptr(), T, 2, 0,
+                                                 ci.data_ptr(), cd.data_ptr(), ck.data_ptr(),
+                                                 C.c_float(args.ratio), sptr))
+            torch.cuda.synchronize()
+            res["sampled_rows_equal_plain_call"] = bool(
+                torch.equal(idx[pick], ci) and torch.equal(dst[pick], cd)
+                and torch.equal(keep[pick], ck))
+    finally:
+        _lib.check(lib.ph_db_free(h))
+    return res
+
+
 def main():
     args = parse()
     # RCCL shares buffers between the ranks' processes through dmabuf handles on this platform
@@ -534,6 +601,7 @@ def main():
     value = evals_per_step_all * steps_run / elapsed
 
     sharded = bench_train_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr)
+    framed = bench_frame_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr)
     ransac = bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr)
 
     out = None
@@ -740,6 +808,7 @@ def main():
                 "parallelism": f"frames x{world} (no collective)",
             },
             "us_per_frame": elapsed / steps_run / F * 1e6,
+            "frame_sharded_database": framed,
             "train_sharded": sharded,
             "per_call": per_call,
             "popcount_kernel": popcount,
