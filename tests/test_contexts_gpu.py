@@ -232,3 +232,77 @@ def test_python_context_wrapper(posehip):
     ctx.close()                               # idempotent
     with pytest.raises(posehip.PosehipError):
         ctx.__enter__()
+
+
+def test_settings_and_profiling_are_per_context(posehip):
+    """The k-NN path setting and the profiling switch belong to a context: forcing the matrix
+    cores and recording events in one context changes nothing in another or in the default."""
+    lib = posehip.load()
+    q, t = datagen.random_descriptors(600, 31), datagen.random_descriptors(700, 32)
+    want = orc.knn(q, t, 2)
+    a, b = C.c_void_p(), C.c_void_p()
+    posehip.check(lib.ph_ctx_create(0, C.byref(a)))
+    posehip.check(lib.ph_ctx_create(0, C.byref(b)))
+    ms = C.c_float(-1)
+    try:
+        posehip.check(lib.ph_ctx_make_current(a))
+        posehip.check(lib.ph_knn_set_path(2))
+        posehip.check(lib.ph_set_profiling(1))
+        gi, gd = _knn_host(posehip, q, t, 2)
+        assert lib.ph_knn_last_path() == 1                      # matrix cores, as forced in a
+        posehip.check(lib.ph_knn_last_timing(C.byref(ms), None))
+        assert ms.value > 0
+        assert np.array_equal(gi, want[0]) and np.array_equal(gd, want[1])
+        posehip.check(lib.ph_ctx_make_current(b))
+        gi, gd = _knn_host(posehip, q, t, 2)
+        assert lib.ph_knn_last_path() == 0                      # b picks by size: popcount kernel
+        assert lib.ph_knn_last_timing(C.byref(ms), None) == 1   # b never enabled profiling
+        assert np.array_equal(gi, want[0]) and np.array_equal(gd, want[1])
+        posehip.check(lib.ph_ctx_make_current(None))
+        gi, gd = _knn_host(posehip, q, t, 2)
+        assert lib.ph_knn_last_path() == 0 and lib.ph_knn_last_timing(C.byref(ms), None) == 1
+        posehip.check(lib.ph_ctx_make_current(a))
+        assert lib.ph_knn_last_path() == 1                      # a's own record is untouched
+    finally:
+        lib.ph_ctx_make_current(None)
+        lib.ph_ctx_destroy(a)
+        lib.ph_ctx_destroy(b)
+
+
+def test_contexts_created_used_and_destroyed_concurrently(posehip):
+    """Four threads each create a context, run a few calls in it and destroy it, twenty times
+    over, while the main thread keeps calling through the default context: the registry and
+    the per-context locks keep every result right and nothing is left behind."""
+    lib = posehip.load()
+    q, t = datagen.random_descriptors(300, 41), datagen.random_descriptors(350, 42)
+    want = orc.knn(q, t, 2)
+    want_cc = orc.match(q, t[:300], cross_check=True)
+    errors, done = [], []
+
+    def worker(w):
+        try:
+            for rep in range(20):
+                c = C.c_void_p()
+                posehip.check(lib.ph_ctx_create(0, C.byref(c)))
+                posehip.check(lib.ph_ctx_make_current(c))
+                gi, gd = _knn_host(posehip, q, t, 2)
+                assert np.array_equal(gi, want[0]) and np.array_equal(gd, want[1])
+                assert _crosscheck_host(posehip, q, t[:300]) == want_cc
+                if rep % 2:        # destroy while current, or after handing the thread back
+                    posehip.check(lib.ph_ctx_make_current(None))
+                posehip.check(lib.ph_ctx_destroy(c))
+                assert lib.ph_ctx_current() is None and lib.ph_ctx_device(c) == -1
+            done.append(w)
+        except Exception as e:
+            errors.append((w, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(4)]
+    for th in threads:
+        th.start()
+    while any(th.is_alive() for th in threads):
+        gi, gd = _knn_host(posehip, q, t, 2)
+        assert np.array_equal(gi, want[0]) and np.array_equal(gd, want[1])
+    for th in threads:
+        th.join(timeout=100)
+    assert not errors, errors
+    assert sorted(done) == [0, 1, 2, 3]
