@@ -61,9 +61,11 @@ typedef struct {
 
 /* ---- lifetime ------------------------------------------------------------ */
 
-/* Binds the calling process to one GPU and creates the library's stream and
- * workspace.  Replaces the matcher construction at src/cereal_box.cpp:53.
- * May be called again with the same device (no-op). */
+/* Creates the default context: binds it to one GPU and creates its stream and
+ * workspace (further GPUs, or further concurrent callers: ph_ctx_create below).
+ * Replaces the matcher construction at src/cereal_box.cpp:53.  May be called
+ * again with the same device (no-op).  ph_shutdown releases the default context
+ * and the resident train sets uploaded through it. */
 ph_status ph_init(int device);
 void ph_shutdown(void);
 const char *ph_last_error_string(void);
@@ -180,9 +182,10 @@ ph_status ph_db_knn_hamming256_dev(const ph_db *db, const void *d_query, int64_t
  * report global indices).  d_keep may be NULL; otherwise k must be 2 and
  * d_keep[i] (one byte per query) is set to 1 iff the ratio test with `ratio`
  * passes.  Enqueues on `stream` (a hipStream_t, NULL = library stream) and
- * returns without waiting.  The library workspace is shared: a call on another
- * stream than the previous one is ordered after that one's work (calls never
- * run concurrently with each other). */
+ * returns without waiting.  A context's workspace is shared by its calls: a call
+ * on another stream than the context's previous one is ordered after that one's
+ * work (calls through ONE context never run concurrently with each other; calls
+ * through different contexts do). */
 ph_status ph_knn_hamming256_dev(const void *d_query, int64_t nq, const void *d_train, int64_t nt,
                                 int k, int32_t train_index_base, int32_t *d_out_idx,
                                 int32_t *d_out_dist, uint8_t *d_keep, float ratio, void *stream);
