@@ -706,6 +706,9 @@ def main():
         if mfma_path:
             flops = 512.0 * nq * nt * F  # 256 multiply-adds per pair
             peak_tflops = 10000.0        # dense FP4 MFMA peak of MI355X
+            # and what this GPU sustains on the kernel's MFMA alone, at the clock it holds
+            bare = C.c_double(0)
+            _lib.check(lib.ph_mfma_fp4_peak(3000, C.byref(bare)))
             roofline = {
                 "bound": "mfma",
                 "kernel": kernel_name,
@@ -722,6 +725,12 @@ def main():
                 "merge_kernel_ms": merge_ms,
                 "event_interval_overhead_ms": event_ms,
                 "peak_source": "dense FP4 MFMA peak (~10 PFLOP/s at 2.4 GHz)",
+                "peak_measured": bare.value / 1e12,
+                "frac_of_measured_peak": flops / (kernel_ms * 1e-3) / bare.value,
+                "peak_measured_source": "measured live: v_mfma_scale_f32_32x32x64_f8f6f4 alone on "
+                                        "random FP4 operands, 4 independent chains, 2 waves/SIMD "
+                                        "on every CU (the clock the chip holds under MFMA load is "
+                                        "below the 2.4 GHz of the spec figure)",
                 "hbm_algorithmic_GBps": 128.0 * (nq + nt) * F / (kernel_ms * 1e-3) / 1e9,
             }
         else:

@@ -380,6 +380,14 @@ int ph_knn_last_path(void);
  * matcher's roofline is this figure / 16.  Blocks until measured. */
 ph_status ph_valu_popcount_peak(int iters, double *lane_ops_per_s);
 
+/* Sustained rate, in FLOP per second, of the matrix-core distance kernel's one MFMA
+ * (v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 operands of +-4 at random) with nothing
+ * else in the loop: four independent chains, two waves per SIMD on every CU, `iters` x
+ * 16 MFMAs per wave.  The dense-FP4 spec peak assumes the nominal clock; this is what
+ * the chip sustains at the clock it holds under that load, i.e. the ceiling of the
+ * matrix-core matcher on this GPU.  Blocks until measured. */
+ph_status ph_mfma_fp4_peak(int iters, double *flop_per_s);
+
 /* Sustained fp64 VALU rates, in lane-operations per second, with 8 waves per SIMD on
  * every CU: v_fma_f64 alone (two FLOP per lane-operation: the fp64 vector peak), and the
  * v_mul_f64 + v_add_f64 mix (one FLOP each) that the RANSAC-EPnP solve is made of, being

@@ -104,6 +104,7 @@ SIGNATURES = {
     "ph_knn_last_timing_overhead": (C.c_int, [_f32p]),
     "ph_valu_popcount_peak": (C.c_int, [C.c_int, _f64p]),
     "ph_valu_fp64_peak": (C.c_int, [C.c_int, _f64p, _f64p]),
+    "ph_mfma_fp4_peak": (C.c_int, [C.c_int, _f64p]),
     "ph_ransac_set_solve_path": (C.c_int, [C.c_int]),
     "ph_ransac_last_timing": (C.c_int, [_f32p, _f32p, _f32p]),
 }

@@ -68,4 +68,10 @@ hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const 
                                   float ratio, hipStream_t stream, hipEvent_t *events = nullptr,
                                   bool uniform_frames = false);
 
+// Sustained rate of the distance kernel's MFMA alone (v_mfma_scale_f32_32x32x64_f8f6f4 on FP4
+// operands of +-4 at random, four independent chains, two waves per SIMD on every CU), in
+// FLOP per second.  d_scratch: n_cus * 2 * 256 floats.  Blocks until measured.
+hipError_t mfma_fp4_peak(int n_cus, int iters, float *d_scratch, hipStream_t stream,
+                         double *flop_per_s);
+
 } // namespace posehip

@@ -614,4 +614,84 @@ hipError_t knn_mfma_frames_launch(const MfmaPlan &p, const void *d_query, const 
     return record(events, 3, stream);
 }
 
+// ---- FP4 MFMA peak ----------------------------------------------------------------
+// Nothing but the distance kernel's MFMA: four independent chains of four
+// v_mfma_scale_f32_32x32x64_f8f6f4 per iteration (the same scales, FP4 operands of +-4 at
+// random, held in registers), two waves per SIMD on every CU as in the distance kernel.
+// What it sustains is the ceiling the chip gives this instruction at the clock it holds
+// under that load; the dense-FP4 spec figure assumes the nominal clock.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, unsigned seed, int iters)
+{
+    // operand nibbles 0x6 (+4) / 0xE (-4), sign bits from a hash of the thread id
+    unsigned x = (threadIdx.x + 1u) * 2654435761u ^ seed;
+    i32x8 a[4], b[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        unsigned w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            x ^= x << 13;
+            x ^= x >> 17;
+            x ^= x << 5;
+            w[i] = 0x66666666u | (x & 0x88888888u);
+        }
+        a[s] = i32x8{(int)w[0], (int)w[1], (int)w[2], (int)w[3], 0, 0, 0, 0};
+        b[s] = i32x8{(int)w[4], (int)w[5], (int)w[6], (int)w[7], 0, 0, 0, 0};
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            acc[j][i] = (float)(i + j);
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) // consecutive MFMAs belong to different chains
+                acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                    a[s], b[(s + j) & 3], acc[j], 4, 4, 0, MF_SCALE_A, 0, MF_SCALE_B);
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            r += acc[j][i];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+hipError_t mfma_fp4_peak(int n_cus, int iters, float *d_scratch, hipStream_t stream,
+                         double *flop_per_s)
+{
+    const int blocks = n_cus * 2; // 2 workgroups x 4 waves per CU = 2 waves per SIMD
+    hipEvent_t e0, e1;
+    hipError_t e;
+    if ((e = hipEventCreate(&e0)) != hipSuccess)
+        return e;
+    if ((e = hipEventCreate(&e1)) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return e;
+    }
+    float best = 0.f;
+    for (int r = 0; r < 8; r++) { // the first passes settle the clock under this load
+        (void)hipEventRecord(e0, stream);
+        mfma_peak_kernel<<<blocks, 256, 0, stream>>>(d_scratch, 0x9e3779b9u + r, iters);
+        (void)hipEventRecord(e1, stream);
+        if ((e = hipEventSynchronize(e1)) != hipSuccess)
+            break;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r >= 4 && (best == 0.f || ms < best))
+            best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess)
+        return e;
+    // one MFMA = 32 x 32 x 64 multiply-adds
+    *flop_per_s = (double)blocks * 4.0 * (double)iters * 16.0 * 2.0 * 32 * 32 * 64 / (best * 1e-3);
+    return hipGetLastError();
+}
+
 } // namespace posehip

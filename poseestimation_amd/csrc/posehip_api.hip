@@ -1219,6 +1219,22 @@ ph_status ph_valu_fp64_peak(int iters, double *fma_lane_ops_per_s,
     return PH_OK;
 }
 
+ph_status ph_mfma_fp4_peak(int iters, double *flop_per_s)
+{
+    Call call;
+    if (call.st != PH_OK)
+        return call.st;
+    Context &c = *call.c;
+    ph_status s = PH_OK;
+    if (iters < 1 || !flop_per_s)
+        return fail(PH_ERR_INVALID_ARG, "iters must be >= 1 and the output non-null");
+    if ((s = scratch_guard(c, c.stream)) != PH_OK) // tmp_i is cross-check workspace as well
+        return s;
+    PH_HIP(c.tmp_i.reserve((size_t)c.n_cus * 2 * 256 * sizeof(float)));
+    PH_HIP(mfma_fp4_peak(c.n_cus, iters, (float *)c.tmp_i.p, c.stream, flop_per_s));
+    return PH_OK;
+}
+
 ph_status ph_ransac_set_solve_path(int mode)
 {
     if (mode < 0 || mode > 3)

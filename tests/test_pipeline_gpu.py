@@ -84,3 +84,22 @@ def test_frames_to_poses(posehip):
         # stage 3: the wireframe's model matrix from the estimate (src/cereal_box.cpp:286)
         M_est = g.model_matrix_from_pose(rvec, tvec)
         assert np.abs(M_est - truth[f]).max() < 1e-2
+
+
+def test_measured_ceilings_are_plausible(posehip):
+    """The three live ceilings the benchmark divides by: integer VALU (xor + popcount mix),
+    fp64 VALU (fma; mul + add) and the FP4 MFMA of the matrix-core matcher.  Each must lie
+    between a third of and slightly above the figure the MI355X data sheet implies; invalid
+    arguments are refused."""
+    import ctypes as C
+    lib = posehip.load()
+    ops, fma, mix, mf = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    posehip.check(lib.ph_valu_popcount_peak(500, C.byref(ops)))
+    posehip.check(lib.ph_valu_fp64_peak(500, C.byref(fma), C.byref(mix)))
+    posehip.check(lib.ph_mfma_fp4_peak(500, C.byref(mf)))
+    spec_int = 256 * 4 * 16 * 2.4e9          # lane-ops/s: 1024 SIMDs x 16 lanes per clock at 2.4 GHz
+    assert spec_int / 3 <= ops.value <= spec_int * 1.2
+    assert 78.6e12 / 2 / 3 <= fma.value <= 78.6e12 / 2 * 1.1      # lane-ops/s; 2 FLOP each
+    assert mix.value <= fma.value * 1.05 and mix.value >= fma.value / 2
+    assert 10e15 / 3 <= mf.value <= 10e15 * 1.05
+    assert lib.ph_mfma_fp4_peak(0, C.byref(mf)) == 1 and lib.ph_mfma_fp4_peak(10, None) == 1
