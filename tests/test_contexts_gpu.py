@@ -306,3 +306,21 @@ def test_contexts_created_used_and_destroyed_concurrently(posehip):
         th.join(timeout=100)
     assert not errors, errors
     assert sorted(done) == [0, 1, 2, 3]
+
+
+def test_context_stress_program():
+    """tests/context_stress.cpp, a C++ host on the C ABI alone: four threads create, bind, use
+    and destroy ten contexts each (own and shared resident train sets, matcher and pose calls,
+    per-context settings) while two more threads call through the default context and poll
+    the registry; every result must equal the default context's.  The same program runs under
+    ASan + UBSan with the library's host code instrumented (tests/tools/build_sanitized.sh)."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "context_stress")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe, "4", "10"], capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line == {"threads": 4, "contexts_per_thread": 10, "failures": 0}
