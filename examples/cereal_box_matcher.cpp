@@ -96,10 +96,10 @@ int main(int argc, char **argv)
     dump(reinterpret_cast<const std::int32_t *>(cc.data()), cc.size() * 4);
     dump(reinterpret_cast<const std::int32_t *>(ratio.data()), ratio.size() * 4);
 
-    long long digest = 0;
+    unsigned long long digest = 0; // wraps modulo 2^64
     for (const DMatch &m : matches)
-        digest = digest * 1000003 + m.queryIdx * 131 + m.trainIdx * 17 + (int)m.distance;
-    std::printf("matches %zu good %zu crosscheck %zu ratio %zu digest %lld\n", matches.size(), good_matches.size(),
+        digest = digest * 1000003ull + (unsigned long long)(m.queryIdx * 131 + m.trainIdx * 17 + (int)m.distance);
+    std::printf("matches %zu good %zu crosscheck %zu ratio %zu digest %llu\n", matches.size(), good_matches.size(),
                 cc.size(), ratio.size(), digest);
     for (int i = 0; i < 5; i++)
         std::printf("match[%d] = (%d, %d, %g)\n", i, matches[i].queryIdx, matches[i].trainIdx, matches[i].distance);
