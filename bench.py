@@ -355,7 +355,7 @@ def bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr):
             "batched_poses_per_s": 256 / tb, "batched_call_ms": tb * 1e3,
             "single_call_ms": t1 * 1e3,
         }
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU beside it: at N = 1 only
         import oracle_bind as orc
         try:
             cores = len(os.sched_getaffinity(0))
@@ -754,7 +754,7 @@ def main():
             }
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:   # at N = 1 only; the other ranks would wait
             import oracle_bind as orc
             try:
                 cores = len(os.sched_getaffinity(0))
