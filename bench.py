@@ -456,6 +456,56 @@ def bench_train_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr):
     return res
 
 
+def bench_reference_frame(args, torch, lib, _lib, dev, sptr):
+    """BASELINE configs[0], the reference's own per-frame workload: 500 ORB descriptors against
+    500 with BFMatcher(NORM_HAMMING, crossCheck=True).match (matcher.py:18,21) -- one frame per
+    host call through the C ABI (PCIe, launch and synchronisation included), and 256 such
+    frames resident in HBM in one batched launch.  Rank 0 only: latency, not a scaling figure."""
+    import datagen
+    from poseestimation_amd.distributed import match_crosscheck_frames
+    n, F = 500, 256
+    q = [datagen.random_descriptors(n, 9000 + f) for f in range(8)]
+    t = [datagen.perturbed_copy(x, 9100 + f) for f, x in enumerate(q)]
+    u8 = C.POINTER(C.c_uint8)
+    out = (_lib.DMatchC * n)()
+    n_out = C.c_int(0)
+    fn = lib.ph_match_crosscheck_hamming256
+
+    def one(f):
+        st = fn(q[f].ctypes.data_as(u8), n, 32, t[f].ctypes.data_as(u8), n, 32, out, C.byref(n_out))
+        if st != 0:
+            _lib.check(st)
+
+    for f in range(8):
+        one(f)
+    best = float("inf")
+    for _ in range(3):
+        c0 = time.perf_counter()
+        for r in range(200):
+            one(r % 8)
+        best = min(best, (time.perf_counter() - c0) / 200)
+    kept = n_out.value
+    d_q = torch.from_numpy(np.concatenate([q[f % 8] for f in range(F)])).to(dev)
+    d_t = torch.from_numpy(np.concatenate([t[f % 8] for f in range(F)])).to(dev)
+    off = np.arange(F + 1, dtype=np.int32) * n
+    match_crosscheck_frames(d_q, off, d_t, off)
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    for _ in range(20):
+        idx, _d = match_crosscheck_frames(d_q, off, d_t, off)
+    torch.cuda.synchronize()
+    batched = (time.perf_counter() - c0) / 20
+    return {
+        "workload": f"{n} x {n} ORB descriptors, BFMatcher(NORM_HAMMING, crossCheck=True).match "
+                    f"(BASELINE configs[0]; the pose half is ransac_epnp.solvepnp_ransac_host_calls)",
+        "single_call_us": best * 1e6, "matches_kept_last_call": kept,
+        "batched_us_per_frame": batched / F * 1e6, "batched_frames": F,
+        "batched_matches_kept_per_frame": int((idx >= 0).sum().item()) / F,
+        "what": "single: host buffers through the C ABI, one frame per call; batched: 256 frames "
+                "resident in HBM, one ph_match_crosscheck_hamming256_frames_dev launch",
+    }
+
+
 def bench_frame_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr):
     """The frame-sharded form of BASELINE configs[3]: 4096 frames x 2000 descriptors against a
     50k-row model database, 512 frames per rank at 8 ranks.  The database is uploaded once and
@@ -602,6 +652,7 @@ def main():
 
     sharded = bench_train_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr)
     framed = bench_frame_sharded(args, torch, dist, lib, _lib, dev, rank, world, sptr)
+    ref_frame = bench_reference_frame(args, torch, lib, _lib, dev, sptr) if rank == 0 else None
     ransac = bench_ransac(args, torch, dist, lib, _lib, dev, rank, world, sptr)
 
     out = None
@@ -817,6 +868,7 @@ def main():
                 "parallelism": f"frames x{world} (no collective)",
             },
             "us_per_frame": elapsed / steps_run / F * 1e6,
+            "reference_frame_crosscheck": ref_frame,
             "frame_sharded_database": framed,
             "train_sharded": sharded,
             "per_call": per_call,
