@@ -62,8 +62,8 @@ def parse():
     ap.add_argument("--ransac-steps", type=int, default=10)
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the default) or gloo (rehearsing N ranks on fewer GPUs)")
-    ap.add_argument("--min-seconds", type=float, default=0.5,
-                    help="shortest timed region; steps are raised to reach it")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="length of the sustained region timed beside the exact --steps region")
     ap.add_argument("--min-warmup-seconds", type=float, default=0.05)
     ap.add_argument("--shard-nq", type=int, default=1_000_000,
                     help="train-sharded leg: queries (replicated on every rank)")
